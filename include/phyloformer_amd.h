@@ -1,0 +1,165 @@
+/*
+ * phyloformer_amd — C ABI of the MI355X (gfx950) Phyloformer inference path.
+ *
+ * One shared library (libphyloformer_amd.so, built by hipcc for gfx950) owns
+ * device memory, the HIP stream, the pre-split weights and every kernel.  The
+ * Python host code (phyloformer_amd/engine.py) binds these symbols with
+ * ctypes; nothing in the signatures is a torch / numpy type.
+ *
+ * What each entry point replaces in the reference (lucanest/Phyloformer; the
+ * reference has no FFI layer of its own, its boundary is Python-level —
+ * SURVEY.md §8b):
+ *
+ *   pf_create            Phyloformer(**hp) + load_state_dict + .to(device) + .eval()
+ *                        infer_alns.py:71-86, phyloformer/model.py:109-164
+ *   pf_forward           model(aln[None, :].float())
+ *                        infer_alns.py:112 -> phyloformer/model.py:166-187
+ *                        (embedding :173, pair expansion :175, 6 x PhyloformerLayer
+ *                        :87-106 with ScaledLinearAttention attention.py:160-197,
+ *                        pwFNN + Softplus :182, site mean :185)
+ *   pf_forward_sharded   the same forward for a contiguous block of sites of every
+ *                        pair; row-attention statistics (attention.py:183-190 with
+ *                        dim=-2 = sites, model.py:91) and the final site sums
+ *                        (model.py:185) are all-reduced over RCCL.  The reference has
+ *                        no multi-device inference; this is the build's site-sharding.
+ *   pf_destroy           garbage collection of the nn.Module
+ *
+ * Conventions
+ *   - every function returns PF_OK (0) or a negative pf_status; nothing throws
+ *     across the ABI; pf_last_error() gives the message for the last failure on
+ *     that handle (or, with NULL, the last failure of pf_create on this thread);
+ *   - the caller owns all host buffers; the library owns all device memory and
+ *     copies the weights at pf_create;
+ *   - a handle is bound to one device and one stream and is not thread-safe;
+ *     distinct handles are independent;
+ *   - residues are alphabet indices 0..21 in the order "ARNDCQEGHILKMFPSTWYVX-"
+ *     (phyloformer/data.py:7); the one-hot tensor of the reference never exists;
+ *   - pairs are enumerated (i, j), i < j, lexicographically (model.py:13-17),
+ *     P = N(N-1)/2 outputs per alignment.
+ */
+#ifndef PHYLOFORMER_AMD_H
+#define PHYLOFORMER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+
+typedef enum pf_status {
+    PF_OK = 0,
+    PF_EINVAL = -1,  /* bad dims, residue index > 21, N > max_seqs, unsupported architecture */
+    PF_EHIP = -2,    /* a HIP runtime call or kernel launch failed */
+    PF_ERCCL = -3,   /* RCCL missing or a collective failed */
+    PF_ENOMEM = -4,  /* device or host allocation failed */
+    PF_ESTATE = -5   /* call not valid in the handle's current state */
+} pf_status;
+
+/* Flat fp32 weight blob.  Order (phyloformer_amd/weights.py::blob_layout):
+ *   embedding_block.0.weight [E][22], .bias [E];
+ *   per block b, for a in (row, col):
+ *       a_norm.weight [E], a_norm.bias [E],
+ *       q_proj.weight [H][E], q_proj.bias [H], k_proj.weight [H][E], k_proj.bias [H],
+ *       v_proj.weight [E][E], v_proj.bias [E], out_proj.weight [E][E], out_proj.bias [E];
+ *     then ffn_norm.weight [E], ffn_norm.bias [E],
+ *       ffn.0.weight [4E][E], ffn.0.bias [4E], ffn.3.weight [E][4E], ffn.3.bias [E];
+ *   pwFNN.0.weight [E], pwFNN.0.bias [1].
+ * The kernels are specialised for E = 64, H = 4 (all shipped checkpoints);
+ * other values are refused with PF_EINVAL. */
+typedef struct pf_weights_t {
+    int32_t n_blocks;
+    int32_t n_heads;
+    int32_t embed_dim;
+    int32_t n_alphabet;     /* 22 */
+    const float* blob;
+    uint64_t blob_len;      /* number of floats */
+} pf_weights_t;
+
+typedef struct pf_handle pf_handle_t;
+
+/* Expected blob_len for an architecture, so bindings can check before calling. */
+uint64_t pf_blob_len(int32_t n_blocks, int32_t n_heads, int32_t embed_dim);
+
+int pf_abi_version(void);
+
+/* Create a handle on HIP device `device`: uploads the weights, builds the
+ * embedding table and the bf16 hi/lo MFMA operand images.  Fails with PF_EHIP
+ * if no gfx950 device is present: there is no CPU fallback. */
+int pf_create(const pf_weights_t* w, int device, pf_handle_t** out);
+int pf_destroy(pf_handle_t* h);
+const char* pf_last_error(const pf_handle_t* h);
+
+/* Options (before or between forwards):
+ *   "max_seqs"   int   sequence cap, default 200 (model.py:39); 0 lifts it
+ *   "gemm"       int   0 = split-bf16 x3 MFMA (default), 1 = exact fp32 MFMA
+ *   "profile"    int   1 = bracket every launch with HIP events (see pf_profile_*)
+ *   "debug_keep" int   1 = keep per-layer activations for pf_debug_read
+ */
+int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
+
+/* Forward pass.  idx: host uint8 [B][N][L]; out: host float [B][P].
+ * Synchronous: returns after `out` is filled.
+ * Errors: PF_EINVAL for B < 1, N < 2, L < 1, N > max_seqs, or an index > 21. */
+int pf_forward(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t L, float* out);
+
+/* Same with device-resident buffers, asynchronous on the handle's stream
+ * (used by the benchmark so the timed region starts with inputs in HBM).
+ * d_idx: device uint8 [B][N][L]; d_out: device float [B][P]. */
+int pf_forward_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N, int32_t L,
+                      float* d_out);
+
+/* Site-sharded forward: this rank holds sites [l_begin, l_end) of an alignment
+ * with L_total sites.  idx: host uint8 [B][N][l_end - l_begin].  Every rank
+ * receives the full result in out [B][P].  Requires pf_comm_init when the
+ * communicator has more than one rank. */
+int pf_forward_sharded(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N,
+                       int32_t l_begin, int32_t l_end, int32_t L_total, float* out);
+int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N,
+                              int32_t l_begin, int32_t l_end, int32_t L_total, float* d_out);
+
+/* RCCL bootstrap (one process per GPU).  Rank 0 calls pf_comm_unique_id and
+ * ships the PF_UNIQUE_ID_BYTES bytes to the other ranks by any means
+ * (torch.distributed store, file, socket); every rank then calls pf_comm_init. */
+#define PF_UNIQUE_ID_BYTES 128
+int pf_comm_unique_id(void* id_out);
+int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t world_size);
+int pf_comm_destroy(pf_handle_t* h);
+
+/* Stream / device access for callers that time with HIP events. */
+int pf_synchronize(pf_handle_t* h);
+int pf_get_stream(pf_handle_t* h, void** hip_stream_out);
+int pf_device_malloc(pf_handle_t* h, size_t bytes, void** out);
+int pf_device_free(pf_handle_t* h, void* p);
+int pf_memcpy_h2d(pf_handle_t* h, void* dst, const void* src, size_t bytes);
+int pf_memcpy_d2h(pf_handle_t* h, void* dst, const void* src, size_t bytes);
+
+/* Per-kernel HIP-event timing ("profile" = 1).  Names: "embed", "rowfin",
+ * "colstats", "colfin", "main", "allreduce".  Totals accumulate until reset. */
+int pf_profile_reset(pf_handle_t* h);
+int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double* total_ms);
+
+/* Debug taps ("debug_keep" = 1), valid after a forward:
+ *   "x<k>"    float [B][P][Lloc][64]  residual stream after k main kernels
+ *             (x0 = embedding + pair expansion, x<k> = output of block k-1)
+ *   "srow<k>" float [B][P][72]   row statistics feeding block k
+ *   "ctx<k>"  float [B][Lloc][64] column context of block k
+ * Returns the number of floats written (<= cap) or a negative status. */
+int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap);
+
+/* Device properties the benchmark prints: name, CU count, HBM bytes. */
+int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_count,
+                   uint64_t* hbm_bytes);
+
+/* Hardware-layout self test: one wave exercises the cross-lane primitives and one
+ * MFMA with known operands; `out` receives 2304 floats (layout in
+ * phyloformer_amd/csrc/pf_device.hip.h::k_selftest).  tests/test_gpu_selftest.py
+ * checks them against the layout the kernels assume. */
+int pf_selftest(pf_handle_t* h, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYLOFORMER_AMD_H */

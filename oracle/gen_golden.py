@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Generate ``tests/golden/*`` by running the REFERENCE on CPU.  Build container only.
+
+Imports ``/root/reference`` (read-only, needs an empty ``dendropy`` stub because
+phyloformer/data.py:3 imports it at module top) and records what the reference
+computes, so that the oracle and the device path can be pinned to it on
+machines where the reference does not exist (the GPU box).  Only *data*
+(inputs and expected outputs) is written — no reference source.
+
+    python oracle/gen_golden.py [--only e2e,taps,configs,phy,batch] [--big]
+
+``--big`` additionally produces the 60×2000 and gapped 200×500 goldens
+(minutes of CPU and tens of GB of RAM).
+"""
+import argparse
+import glob
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+CKPTS = ["pf", "pf_base", "pf_indel", "pf_cherry", "pf_selreg"]
+
+
+def _import_reference():
+    stub = tempfile.mkdtemp(prefix="pf_stub_")
+    os.makedirs(os.path.join(stub, "dendropy"))
+    open(os.path.join(stub, "dendropy", "__init__.py"), "w").close()
+    sys.path.insert(0, stub)
+    sys.path.insert(0, REF)
+    import torch
+    from phyloformer.model import Phyloformer  # noqa
+    from phyloformer.data import load_alignment  # noqa
+    return torch, Phyloformer, load_alignment, stub
+
+
+def _load_model(torch, Phyloformer, name):
+    # same steps as infer_alns.py:71-86
+    ckpt = torch.load(os.path.join(REF, "models", f"{name}.ckpt"), map_location="cpu")
+    model = Phyloformer(**ckpt["hyper_parameters"])
+    model.load_state_dict({k.replace("model.", ""): v for k, v in ckpt["state_dict"].items()
+                           if k != "model.seq2pair"}, strict=False)
+    model.eval()
+    return model
+
+
+def _onehot(torch, idx):
+    # indices uint8[N, L] → float[1, 22, L, N], as data.py:28-29 + infer_alns.py:112
+    t = torch.from_numpy(idx.astype(np.int64))
+    return torch.nn.functional.one_hot(t, num_classes=22).permute(2, 1, 0)[None].float()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="e2e,taps,configs,phy,batch")
+    ap.add_argument("--big", action="store_true")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    os.makedirs(GOLD, exist_ok=True)
+    torch, Phyloformer, load_alignment, stub = _import_reference()
+    torch.manual_seed(0)
+    sys.path.insert(0, REPO)
+    from phyloformer_amd.msa_sim import simulate_alignment, simulate_batch
+
+    models = {}
+
+    def model(name):
+        if name not in models:
+            models[name] = _load_model(torch, Phyloformer, name)
+        return models[name]
+
+    if "e2e" in only:
+        out = {}
+        files = sorted(glob.glob(os.path.join(REF, "data/testdata/msas/*.fa")))
+        with torch.no_grad():
+            for name in CKPTS:
+                t0 = time.time()
+                for f in files:
+                    aln, ids = load_alignment(f)
+                    pred = model(name)(aln[None, :].float())
+                    out[f"{name}/{os.path.basename(f)[:-3]}"] = pred.numpy().astype(np.float32)
+                print(f"e2e {name}: {time.time() - t0:.1f}s", flush=True)
+        np.savez_compressed(os.path.join(GOLD, "e2e_testdata.npz"), **out)
+
+    if "taps" in only:
+        # tiny case with every alphabet letter incl. X and gap; hooks on each sub-block
+        rng = np.random.default_rng(7)
+        idx = rng.integers(0, 22, size=(5, 16)).astype(np.uint8)
+        m = model("pf")
+        taps = {"idx": idx}
+
+        def tm(t):  # [1, E, P, L] → token-major [P, L, E]
+            return t[0].permute(1, 2, 0).contiguous().numpy().astype(np.float32)
+
+        hooks = []
+        for b, blk in enumerate(m.attention_blocks):
+            # x + row_attn(...) is not a module output: reconstruct from the
+            # residual structure (model.py:87-106) with hooks on the norms' inputs
+            hooks.append(blk.col_norm.register_forward_hook(
+                lambda mod, inp, out, b=b: taps.__setitem__(f"block{b}.row", tm(inp[0].transpose(-1, -3)))))
+            hooks.append(blk.ffn_norm.register_forward_hook(
+                lambda mod, inp, out, b=b: taps.__setitem__(f"block{b}.col", tm(inp[0].transpose(-1, -3)))))
+            hooks.append(blk.register_forward_hook(
+                lambda mod, inp, out, b=b: taps.__setitem__(f"block{b}.ffn", tm(out))))
+        hooks.append(m.attention_blocks[0].register_forward_pre_hook(
+            lambda mod, inp: taps.__setitem__("embed", tm(inp[0]))))
+        hooks.append(m.pwFNN[0].register_forward_hook(
+            lambda mod, inp, out: taps.__setitem__("logits", out[0, 0].numpy().astype(np.float32))))
+        with torch.no_grad():
+            taps["dist"] = m(_onehot(torch, idx)).numpy().astype(np.float32)
+        for h in hooks:
+            h.remove()
+        np.savez_compressed(os.path.join(GOLD, "taps_tiny.npz"), **taps)
+        print("taps:", sorted(taps))
+
+    if "batch" in only:
+        # B=2 → [2, P]; N=2 → 0-dim (squeeze, model.py:185)
+        idx = simulate_batch(2, 6, 40, seed=11)
+        x = torch.cat([_onehot(torch, a) for a in idx])
+        with torch.no_grad():
+            yb = model("pf")(x).numpy().astype(np.float32)
+            y2 = model("pf")(_onehot(torch, idx[0, :2])).numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(GOLD, "batch_small.npz"), idx=idx, dist=yb,
+                            idx_n2=idx[0, :2], dist_n2=y2)
+        print("batch:", yb.shape, y2.shape)
+
+    if "configs" in only:
+        out = {}
+        cfgs = [("c2", "pf", 20, 200, 2, False, 3), ("c3", "pf", 60, 500, 3, False, 1)]
+        if args.big:
+            cfgs += [("c4", "pf", 60, 2000, 4, False, 1), ("c5", "pf_indel", 200, 500, 5, True, 1)]
+        for tag, ck, n, l, seed, gaps, count in cfgs:
+            idx = simulate_batch(count, n, l, seed=seed, gaps=gaps)
+            res = []
+            with torch.no_grad():
+                for a in idx:
+                    t0 = time.time()
+                    res.append(model(ck)(_onehot(torch, a)).numpy().astype(np.float32))
+                    print(f"{tag} {n}x{l}: {time.time() - t0:.1f}s", flush=True)
+            out[f"{tag}_idx"] = idx
+            out[f"{tag}_dist"] = np.stack(res)
+        fn = "configs_big.npz" if args.big else "configs.npz"
+        if args.big:
+            out = {k: v for k, v in out.items() if k.startswith(("c4", "c5"))}
+        np.savez_compressed(os.path.join(GOLD, fn), **out)
+
+    if "phy" in only:
+        # the real CLI, one MSA (PHYLIP formatting golden, infer_alns.py:14-25)
+        with tempfile.TemporaryDirectory() as td:
+            ind, outd = os.path.join(td, "in"), os.path.join(td, "out")
+            os.makedirs(ind)
+            src = os.path.join(REF, "data/testdata/msas/0_20_tips.fa")
+            with open(src, "rb") as f, open(os.path.join(ind, "0_20_tips.fa"), "wb") as g:
+                g.write(f.read())
+            env = dict(os.environ, PYTHONPATH=f"{stub}:{REF}")
+            subprocess.run([sys.executable, os.path.join(REF, "infer_alns.py"), "-o", outd,
+                            os.path.join(REF, "models/pf_base.ckpt"), ind], check=True, env=env,
+                           cwd=td)
+            with open(os.path.join(outd, "0_20_tips.phy")) as f, \
+                    open(os.path.join(GOLD, "0_20_tips.pf_base.phy"), "w") as g:
+                g.write(f.read())
+        print("phy written")
+
+
+if __name__ == "__main__":
+    main()

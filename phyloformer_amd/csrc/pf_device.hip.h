@@ -1,0 +1,674 @@
+// Device kernels of the Phyloformer forward pass for gfx950 (MI355X, CDNA4).
+//
+// Data layout in HBM (all fp32 unless noted), Lloc = sites held by this rank:
+//   x     [B][P][Lloc][64]   residual stream, token-major (pair, site, channel)
+//   qrow  [B][P][Lloc][4]    q' = elu(q)+1 of the row attention of the next block to run
+//   qcol  [B][P][Lloc][4]    q' of the column attention of the current block
+//   srow  [B][P][72]         row statistics: S_kv[64] (no v-bias) | S_q[4] | S_k[4]
+//   mrow  [B][P][5][64]      folded row mix  M[h][c] (h<4) and bias row (h=4)
+//   ctx   [B][Lloc][64]      column context ctx[h*16+d], normalised
+//
+// Algebra (reference: phyloformer/attention.py:160-197, model.py:87-106).  With
+// x~ = LayerNorm without affine, and gamma/beta folded into the projections:
+//   row block:  y[l,c] = bo[c] + sum_h q'[l,h] * M[h][c],
+//               M[h][c] = sum_d Wo[c][16h+d] * (S_kv[16h+d] + bv'[16h+d] S_k[h]) / S_k[h] * L / S_q[h]
+//   col block:  y[p,c] = bo[c] + sum_hd Wo[c][hd] * q'[p,h] * ctx[l][hd]
+//               ctx[l][hd] = (sum_c Wv'[hd][c] Z[l][h][c] + bv'[hd] S_k[l][h]) / S_k[l][h] * P / S_q[l][h]
+//               Z[l][h][c] = sum_p k'[p,l,h] x~[p,l,c]          (V projection pulled out of the sum)
+// so the only per-token dense contractions left are the FFN (64->256->64), the
+// column out-projection and the next block's row V/q/k projection: those run
+// on MFMA as split-bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate).
+//
+// MFMA tiling ("token tile" = 32 consecutive sites of one pair, one wave):
+//   v_mfma_f32_32x32x16_bf16, tokens on the N side.  Lane l = (t = l & 31, h = l >> 5)
+//   owns, for token t, the 32 channels kmap(j, h) = 8*(j>>2) + 4*h + (j&3), j = 0..31.
+//   This is at once the B-operand layout (8 consecutive j per K-step), the C/D
+//   layout of a 32-row output tile (row = (r&3) + 8*(r>>2) + 4*h) and a 16-byte
+//   granular global access pattern, so activations never move between lanes:
+//   GEMM1's accumulators feed GEMM2's B operand directly (K order is permuted
+//   identically in the pre-packed A fragments, see pack_frags() on the host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pfk {
+
+constexpr int E = 64;        // embed_dim
+constexpr int NH = 4;        // heads
+constexpr int HD = 16;       // head_dim
+constexpr int FF = 256;      // FFN hidden
+constexpr int NA = 22;       // alphabet
+constexpr int SROW = 72;     // row statistics per pair
+constexpr int MROW = 5 * 64; // folded row mix per pair (4 heads + bias row)
+constexpr float LN_EPS = 1e-5f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// LDS image of one block's MFMA A operands (bf16x8 fragments, 16 B per lane):
+//   W1' : [8 T][4 s][2 hi/lo][64 lanes]      64 KB   (FFN 64->256, LN affine folded)
+//   W2  : [2 To][16 s][2][64]                64 KB   (FFN 256->64)
+//   Woc : [2 To][4 s][2][64]                 16 KB   (column out_proj)
+//   consts (floats): b1'[256] | b2[64] | bqk[8] | head_w[64] | head_b[1] | pad | bo_col[64]
+constexpr int FRAG_W1 = 0;
+constexpr int FRAG_W2 = FRAG_W1 + 8 * 4 * 2 * 64;
+constexpr int FRAG_WO = FRAG_W2 + 2 * 16 * 2 * 64;
+constexpr int FRAG_END = FRAG_WO + 2 * 4 * 2 * 64;          // in bf16x8 units
+constexpr int CONST_B1 = 0, CONST_B2 = 256, CONST_BQK = 320, CONST_HW = 328, CONST_HB = 392,
+              CONST_BOC = 400;
+constexpr int CONST_LEN = 464;                                // floats
+constexpr int MAIN_LDS_BYTES = FRAG_END * 16 + CONST_LEN * 4; // 149,056 B
+constexpr int RVQK_FRAGS = 3 * 4 * 2 * 64;                    // next block's row [Wv';Wq';Wk'] frags
+
+constexpr int MAIN_THREADS = 256;  // 4 waves, one per SIMD, up to 512 VGPRs each
+constexpr int MAIN_WAVES = MAIN_THREADS / 64;
+
+__device__ __forceinline__ int kmap(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// ---- cross-lane helpers -----------------------------------------------------------------
+// v_permlane32_swap(vdst=v, src=v): r[0] = value of lane (l & 31), r[1] = value of lane 32 + (l & 31).
+__device__ __forceinline__ float pair_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pair_other(float v, int h) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return h ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce sum over each row of 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x124>(v);  // row_ror:4
+    v += dpp_f<0x128>(v);  // row_ror:8
+    return v;
+}
+// all-reduce sum over each half-wave (32 lanes): rows {0,1} and rows {2,3}
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- numerics ---------------------------------------------------------------------------
+__device__ __forceinline__ float elu1_acc(float v) { return v > 0.f ? v + 1.f : expf(v); }
+__device__ __forceinline__ float gelu_erf(float v) {
+    return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+// split 8 floats into bf16 hi + bf16 lo (x ~= hi + lo to 2^-17 relative)
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 hh = (__bf16)v[i];
+        hi[i] = hh;
+        lo[i] = (__bf16)(v[i] - (float)hh);
+    }
+}
+
+#define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// acc += (a_hi + a_lo) * (b_hi + b_lo) without the lo*lo term
+__device__ __forceinline__ void mfma3(f32x16& acc, const bf16x8& a_hi, const bf16x8& a_lo,
+                                      const bf16x8& b_hi, const bf16x8& b_lo) {
+    acc = PF_MFMA(a_lo, b_hi, acc);
+    acc = PF_MFMA(a_hi, b_lo, acc);
+    acc = PF_MFMA(a_hi, b_hi, acc);
+}
+
+// LayerNorm without affine over the 64 channels of a token held by lanes (t,0) and (t,1)
+__device__ __forceinline__ void ln_pair(const float (&x)[32], float (&xn)[32]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s += x[j];
+    const float mean = pair_sum(s) * (1.f / 64.f);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        xn[j] = x[j] - mean;
+        v = fmaf(xn[j], xn[j], v);
+    }
+    const float rstd = 1.0f / sqrtf(pair_sum(v) * (1.f / 64.f) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) xn[j] *= rstd;
+}
+
+struct MainArgs {
+    float* x;               // [B][P][Lloc][64] in/out
+    float* qrow;            // [B][P][Lloc][4]  in: q' of this block's row attn; out: next block's
+    const float* qcol;      // [B][P][Lloc][4]
+    const float* mrow;      // [B][P][5][64]
+    const float* ctx;       // [B][Lloc][64]
+    float* srow;            // [B][P][72]  out: statistics for the next block's row attn
+    float* out;             // [B][P]      out (last block): sum_l softplus / L_total
+    const bf16x8* wimg;     // this block's LDS image (FRAG_END fragments) in global memory
+    const float* consts;    // this block's CONST_LEN floats
+    const bf16x8* rvqk;     // RVQK_FRAGS fragments for the next row attn (global, L2-resident)
+    const float* table;     // [22][64] relu(W_emb + b_emb)          (MODE_FIRST)
+    const uint8_t* idx;     // [B][N][Lloc]                           (MODE_FIRST)
+    const int16_t* pair_i;  // [P]                                    (MODE_FIRST)
+    const int16_t* pair_j;  // [P]
+    int B, N, P, Lloc;
+    int store_x_last;       // debug: MODE_LAST also writes x back
+    float inv_L_total;
+};
+
+enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
+
+// One wave owns one (alignment, pair) row at a time and walks its sites in
+// tiles of 32 tokens; waves never synchronise with each other after the LDS
+// image is loaded.
+//   MODE_FIRST: x = embedding pair sum;                      -> row stats of block 0
+//   MODE_MID  : row-apply + col-apply + FFN of block k;      -> row stats of block k+1
+//   MODE_LAST : row-apply + col-apply + FFN of the last block -> softplus head, site mean
+template <int MODE>
+__global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bf16x8* lw = reinterpret_cast<const bf16x8*>(smem);
+    const float* lc = reinterpret_cast<const float*>(smem + FRAG_END * 16);
+
+    if (MODE != MODE_FIRST) {
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const uint4* src = reinterpret_cast<const uint4*>(a.wimg);
+        for (int i = threadIdx.x; i < FRAG_END; i += MAIN_THREADS) dst[i] = src[i];
+    }
+    {
+        float* dc = reinterpret_cast<float*>(smem + FRAG_END * 16);
+        for (int i = threadIdx.x; i < CONST_LEN; i += MAIN_THREADS) dc[i] = a.consts[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = lane & 31;
+    const int h = lane >> 5;
+    const int ntiles = (a.Lloc + 31) >> 5;
+    const int ntasks = a.B * a.P;
+
+    for (int task = blockIdx.x * MAIN_WAVES + wave; task < ntasks; task += gridDim.x * MAIN_WAVES) {
+        const int b = task / a.P;
+        const int p = task - b * a.P;
+        const size_t row0 = (size_t)task * a.Lloc;  // first token of this pair row
+
+        // ---- per-pair operands ------------------------------------------------------------
+        bf16x8 ma_hi[2], ma_lo[2];  // row mix M^T (+ bias row) as A fragments, K padded 5 -> 16
+        if (MODE != MODE_FIRST) {
+            const float* mr = a.mrow + (size_t)task * MROW;
+#pragma unroll
+            for (int To = 0; To < 2; ++To) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = (h == 0 && i < 5) ? mr[i * 64 + 32 * To + t] : 0.f;
+                split8(v, ma_hi[To], ma_lo[To]);
+            }
+        }
+        int ai = 0, aj = 0;
+        if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
+
+        float s_kv[32], s_q[4], s_k[4], s_out = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s_kv[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_q[i] = 0.f; s_k[i] = 0.f; }
+
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int l = tile * 32 + t;
+            const bool valid = l < a.Lloc;
+            const int lc_ = valid ? l : a.Lloc - 1;  // clamped site for gathers
+            const size_t tok = row0 + lc_;
+            float x[32];
+
+            if (MODE == MODE_FIRST) {
+                // embedding lookup + pair expansion (model.py:173-175): x = T[a_i] + T[a_j]
+                const int ri = a.idx[((size_t)b * a.N + ai) * a.Lloc + lc_];
+                const int rj = a.idx[((size_t)b * a.N + aj) * a.Lloc + lc_];
+                const f32x4* ti = reinterpret_cast<const f32x4*>(a.table + ri * 64 + 4 * h);
+                const f32x4* tj = reinterpret_cast<const f32x4*>(a.table + rj * 64 + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    f32x4 u = ti[2 * g], w = tj[2 * g];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] + w[i] : 0.f;
+                }
+            } else {
+                const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tok * 64 + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    f32x4 u = xp[2 * g];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] : 0.f;
+                }
+                // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
+                f32x16 ya[2];  // starts from the column out_proj bias
+#pragma unroll
+                for (int To = 0; To < 2; ++To) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(
+                            lc + CONST_BOC + 32 * To + 8 * q4 + 4 * h);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ya[To][4 * q4 + i] = bb[i];
+                    }
+                }
+                {
+                    const f32x4 qr = *reinterpret_cast<const f32x4*>(a.qrow + tok * 4);
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
+                    v[4] = (h == 0) ? 1.f : 0.f;
+                    v[5] = v[6] = v[7] = 0.f;
+                    bf16x8 qb_hi, qb_lo;
+                    split8(v, qb_hi, qb_lo);
+#pragma unroll
+                    for (int To = 0; To < 2; ++To) mfma3(ya[To], ma_hi[To], ma_lo[To], qb_hi, qb_lo);
+                }
+                // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
+                {
+                    const f32x4 qc = *reinterpret_cast<const f32x4*>(a.qcol + tok * 4);
+                    const f32x4* cp = reinterpret_cast<const f32x4*>(
+                        a.ctx + ((size_t)b * a.Lloc + lc_) * 64 + 4 * h);
+                    float o[32];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        f32x4 u = cp[2 * g];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[4 * g + i] = u[i] * qc[g >> 1];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bf16x8 ob_hi, ob_lo;
+                        split8(&o[8 * s], ob_hi, ob_lo);
+#pragma unroll
+                        for (int To = 0; To < 2; ++To) {
+                            const bf16x8* f = lw + FRAG_WO + ((To * 4 + s) * 2) * 64 + lane;
+                            mfma3(ya[To], f[0], f[64], ob_hi, ob_lo);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 32; ++j) x[j] += ya[j >> 4][j & 15];
+
+                // ---- feed-forward (model.py:101-104): x += W2 gelu(W1' x~ + b1') + b2
+                {
+                    float xn[32];
+                    ln_pair(x, xn);
+                    bf16x8 xb_hi[4], xb_lo[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) split8(&xn[8 * s], xb_hi[s], xb_lo[s]);
+                    f32x16 oa[2];
+#pragma unroll
+                    for (int To = 0; To < 2; ++To) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(
+                                lc + CONST_B2 + 32 * To + 8 * q4 + 4 * h);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) oa[To][4 * q4 + i] = bb[i];
+                        }
+                    }
+#pragma unroll 1
+                    for (int T = 0; T < 8; ++T) {
+                        f32x16 ha;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(
+                                lc + CONST_B1 + 32 * T + 8 * q4 + 4 * h);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ha[4 * q4 + i] = bb[i];
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const bf16x8* f = lw + FRAG_W1 + ((T * 4 + s) * 2) * 64 + lane;
+                            mfma3(ha, f[0], f[64], xb_hi[s], xb_lo[s]);
+                        }
+                        float gv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gv[r] = gelu_erf(ha[r]);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            bf16x8 g_hi, g_lo;
+                            split8(&gv[8 * u], g_hi, g_lo);
+#pragma unroll
+                            for (int To = 0; To < 2; ++To) {
+                                const bf16x8* f =
+                                    lw + FRAG_W2 + ((To * 16 + 2 * T + u) * 2) * 64 + lane;
+                                mfma3(oa[To], f[0], f[64], g_hi, g_lo);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) x[j] += oa[j >> 4][j & 15];
+                }
+            }
+
+            if (MODE != MODE_LAST) {
+                // ---- statistics of the next block's row attention (attention.py:163-190)
+                float xn[32];
+                ln_pair(x, xn);
+                f32x16 va[3];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    va[0][r] = 0.f;
+                    va[1][r] = 0.f;
+                    va[2][r] = (r < 4) ? lc[CONST_BQK + 4 * h + r] : 0.f;  // rows 0-3 q, 4-7 k
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 xb_hi, xb_lo;
+                    split8(&xn[8 * s], xb_hi, xb_lo);
+#pragma unroll
+                    for (int T = 0; T < 3; ++T) {
+                        const bf16x8* f = a.rvqk + ((T * 4 + s) * 2) * 64 + lane;
+                        mfma3(va[T], f[0], f[64], xb_hi, xb_lo);
+                    }
+                }
+                float qk[4], ot[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qk[i] = elu1_acc(va[2][i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ot[i] = pair_other(qk[i], h);
+                float qn[4], kn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    qn[i] = h ? ot[i] : qk[i];
+                    kn[i] = h ? qk[i] : ot[i];
+                }
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { s_q[i] += qn[i]; s_k[i] += kn[i]; }
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) s_kv[j] = fmaf(kn[j >> 3], va[j >> 4][j & 15], s_kv[j]);
+                    if (h == 0) {
+                        f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
+                        *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = qs;
+                    }
+                    f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        f32x4 u = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                        xo[2 * g] = u;
+                    }
+                }
+            } else {
+                // ---- head: softplus(w.x + b) summed over sites (model.py:182-185)
+                float z = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(lc + CONST_HW + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z = fmaf(w4[i], x[4 * g + i], z);
+                }
+                z = pair_sum(z) + lc[CONST_HB];
+                if (valid) s_out += softplus20(z);
+                if (a.store_x_last && valid) {
+                    f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        f32x4 u = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                        xo[2 * g] = u;
+                    }
+                }
+            }
+        }
+
+        // ---- reduce over the 32 token lanes of each half-wave and publish ------------------
+        if (MODE != MODE_LAST) {
+            float* sr = a.srow + (size_t)task * SROW;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) s_kv[j] = half32_sum(s_kv[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s_q[i] = half32_sum(s_q[i]); s_k[i] = half32_sum(s_k[i]); }
+            if (t == 0) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    f32x4 u = {s_kv[4 * g], s_kv[4 * g + 1], s_kv[4 * g + 2], s_kv[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(sr + 8 * g + 4 * h) = u;
+                }
+                if (h == 0) {
+                    f32x4 u = {s_q[0], s_q[1], s_q[2], s_q[3]};
+                    f32x4 w = {s_k[0], s_k[1], s_k[2], s_k[3]};
+                    *reinterpret_cast<f32x4*>(sr + 64) = u;
+                    *reinterpret_cast<f32x4*>(sr + 68) = w;
+                }
+            }
+        } else {
+            s_out = half32_sum(s_out);
+            if (lane == 0) a.out[task] = s_out * a.inv_L_total;
+        }
+    }
+}
+
+// ---- row finalisation: srow -> mrow ------------------------------------------------------
+struct RowFinArgs {
+    const float* srow;   // [B*P][72]
+    float* mrow;         // [B*P][5][64]
+    const float* woT;    // [64 hd][64 c]  row out_proj, transposed
+    const float* bv;     // [64] folded row v bias
+    const float* bias;   // [64] row out_proj bias
+    int npairs;
+    float L_total;
+};
+
+__global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
+    __shared__ float ctx[4][64];  // 4 pairs per block
+    const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int pr = blockIdx.x * 4 + sub;
+    const bool ok = pr < a.npairs;
+    if (ok) {
+        const float* s = a.srow + (size_t)pr * SROW;
+        const int hh = c >> 4;
+        const float sk = s[68 + hh], sq = s[64 + hh];
+        // (k / sum k)^T v, then q / mean(q): attention.py:183-192
+        ctx[sub][c] = (s[c] + a.bv[c] * sk) / sk * (a.L_total / sq);
+    }
+    __syncthreads();
+    if (ok) {
+        float* m = a.mrow + (size_t)pr * MROW;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc = fmaf(a.woT[(16 * hh + d) * 64 + c], ctx[sub][16 * hh + d], acc);
+            m[hh * 64 + c] = acc;
+        }
+        m[4 * 64 + c] = a.bias[c];
+    }
+}
+
+// ---- column statistics -------------------------------------------------------------------
+struct ColStatsArgs {
+    const float* x;      // [B][P][Lloc][64]
+    const float* qrow;   // [B][P][Lloc][4]
+    const float* mrow;   // [B][P][5][64]
+    float* qcol;         // [B][P][Lloc][4]  out
+    float* part;         // [B][G][Lloc][4*64 + 8]  out: Z~[h][c] | S_q[4] | S_k[4]
+    const float* wqk;    // [8][64] folded col q (rows 0-3) and k (rows 4-7)
+    const float* bqk;    // [8]
+    int B, P, Lloc, G, nchunks;
+};
+constexpr int CPART = 4 * 64 + 8;
+
+// Block = (alignment b, chunk of 4 sites, pair group g); 4 waves stride over the
+// group's pairs.  Lanes: site = lane >> 4, channels 4*(lane & 15) .. +3, so one
+// wave-load is 1 KB contiguous.  Applies the row attention on the fly (it is not
+// materialised in HBM), then LayerNorm -> q', k' -> Z~ += k' x~.
+__global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
+    __shared__ float red[4][64][25];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ts = lane >> 4, cl = lane & 15;
+    int bid = blockIdx.x;
+    const int g = bid % a.G; bid /= a.G;
+    const int chunk = bid % a.nchunks;
+    const int b = bid / a.nchunks;
+    const int l = chunk * 4 + ts;
+    const bool lvalid = l < a.Lloc;
+    const int lcl = lvalid ? l : a.Lloc - 1;
+    const int per = (a.P + a.G - 1) / a.G;
+    const int p0 = g * per, p1 = min(a.P, p0 + per);
+
+    float w[8][4], bq[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(a.wqk + o * 64 + 4 * cl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[o][i] = u[i];
+        bq[o] = a.bqk[o];
+    }
+    float z[4][4], sq[4], sk[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+        sq[hh] = 0.f; sk[hh] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[hh][i] = 0.f;
+    }
+
+    for (int p = p0 + wave; p < p1; p += 4) {
+        const size_t pr = (size_t)b * a.P + p;
+        const size_t tok = pr * a.Lloc + lcl;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + tok * 64 + 4 * cl);
+        const f32x4 qr = *reinterpret_cast<const f32x4*>(a.qrow + tok * 4);
+        const float* m = a.mrow + pr * MROW + 4 * cl;
+        f32x4 y = *reinterpret_cast<const f32x4*>(m + 4 * 64);
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(m + hh * 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = fmaf(qr[hh], mv[i], y[i]);
+        }
+        float xr[4];
+        // x' = x + row attention of this block (bias row included)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[i] = xv[i] + y[i];
+        float s = xr[0] + xr[1] + xr[2] + xr[3];
+        const float mean = row16_sum(s) * (1.f / 64.f);
+        float d[4], v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d[i] = xr[i] - mean; v = fmaf(d[i], d[i], v); }
+        const float rstd = 1.0f / sqrtf(row16_sum(v) * (1.f / 64.f) + LN_EPS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] *= rstd;
+        float qk[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = fmaf(w[o][i], d[i], acc);
+            qk[o] = elu1_acc(row16_sum(acc) + bq[o]);
+        }
+        if (lvalid) {
+            if (cl == 0) {
+                f32x4 qs = {qk[0], qk[1], qk[2], qk[3]};
+                *reinterpret_cast<f32x4*>(a.qcol + tok * 4) = qs;
+            }
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                sq[hh] += qk[hh];
+                sk[hh] += qk[4 + hh];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[hh][i] = fmaf(qk[4 + hh], d[i], z[hh][i]);
+            }
+        }
+    }
+    // cross-wave reduction through LDS, then one partial per (b, g, site)
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][lane][hh * 4 + i] = z[hh][i];
+        red[wave][lane][16 + hh] = sq[hh];
+        red[wave][lane][20 + hh] = sk[hh];
+    }
+    __syncthreads();
+    if (wave == 0 && lvalid) {
+        float* out = a.part + (((size_t)b * a.G + g) * a.Lloc + l) * CPART;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            f32x4 u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                u[i] = red[0][lane][hh * 4 + i] + red[1][lane][hh * 4 + i] +
+                       red[2][lane][hh * 4 + i] + red[3][lane][hh * 4 + i];
+            *reinterpret_cast<f32x4*>(out + hh * 64 + 4 * cl) = u;
+        }
+        if (cl == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                out[256 + k] = red[0][lane][16 + k] + red[1][lane][16 + k] +
+                               red[2][lane][16 + k] + red[3][lane][16 + k];
+        }
+    }
+}
+
+// ---- column finalisation: partials -> ctx --------------------------------------------------
+struct ColFinArgs {
+    const float* part;   // [B][G][Lloc][CPART]
+    float* ctx;          // [B][Lloc][64]
+    const float* wvT;    // [64 c][64 hd] folded col v_proj, transposed
+    const float* bv;     // [64] folded col v bias
+    int B, Lloc, G;
+    float P;
+};
+
+__global__ void __launch_bounds__(256) k_colfin(ColFinArgs a) {
+    __shared__ float zs[CPART];
+    const int site = blockIdx.x;  // b * Lloc + l
+    const int b = site / a.Lloc, l = site - b * a.Lloc;
+    for (int i = threadIdx.x; i < CPART; i += 256) {
+        float acc = 0.f;
+        for (int g = 0; g < a.G; ++g)
+            acc += a.part[(((size_t)b * a.G + g) * a.Lloc + l) * CPART + i];
+        zs[i] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int hd = threadIdx.x, hh = hd >> 4;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) acc = fmaf(a.wvT[c * 64 + hd], zs[hh * 64 + c], acc);
+        const float sq = zs[256 + hh], sk = zs[260 + hh];
+        a.ctx[(size_t)site * 64 + hd] = (acc + a.bv[hd] * sk) / sk * (a.P / sq);
+    }
+}
+
+// ---- self test of the hardware-layout assumptions ------------------------------------------
+// out[0..63]: pair_sum(lane)        expected lane%32 + lane%32+32
+// out[64..127]: pair_other(lane)    expected lane ^ 32
+// out[128..191]: row16_sum(lane)    expected sum of the 16-lane row
+// out[192..255]: half32_sum(lane)   expected sum of the 32-lane half
+// out[256..1279]:  D1 = A1*B, A1[m][k] = m + 32*(k%8), B[k][n] = (k == n%16)  -> m + 32*((n%16)%8)
+// out[1280..2303]: D2 = A2*B, A2[m][k] = k                                    -> n%16
+// both in C/D register order: out[.. + lane*16 + r] = D[(r&3) + 8*(r>>2) + 4*(lane>>5)][lane&31]
+__global__ void k_selftest(float* out) {
+    const int lane = threadIdx.x;
+    out[lane] = pair_sum((float)lane);
+    out[64 + lane] = pair_other((float)lane, lane >> 5);
+    out[128 + lane] = row16_sum((float)lane);
+    out[192 + lane] = half32_sum((float)lane);
+    bf16x8 A1, A2, Bf;
+    const int m = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 8 * kg + i;
+        A1[i] = (__bf16)(float)(m + 32 * (k % 8));      // exact in bf16 (< 256)
+        A2[i] = (__bf16)(float)k;
+        Bf[i] = (__bf16)((k == (m & 15)) ? 1.f : 0.f);  // B[k][n = m] selects k == n % 16
+    }
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+    acc1 = PF_MFMA(A1, Bf, acc1);
+    acc2 = PF_MFMA(A2, Bf, acc2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        out[256 + lane * 16 + r] = acc1[r];
+        out[1280 + lane * 16 + r] = acc2[r];
+    }
+}
+
+}  // namespace pfk

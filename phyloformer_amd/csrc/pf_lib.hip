@@ -1,0 +1,806 @@
+// libphyloformer_amd.so — host side of the C ABI declared in include/phyloformer_amd.h.
+//
+// Owns: the device, one stream, the prepared weights (fp32 folded copies and
+// split-bf16 MFMA fragment images), a grow-only workspace, the optional RCCL
+// communicator and the launch sequence of the forward pass
+// (reference: phyloformer/model.py:166-187).
+//
+// Launch sequence for one batch chunk (nb = n_blocks):
+//   k_main<FIRST>                         embedding + pair sum, row stats of block 0
+//   for k in 0..nb-1:
+//       [all-reduce srow]                 site-sharded runs only
+//       k_rowfin(k)      srow -> mrow
+//       k_colstats(k)    x, qrow, mrow -> qcol, column partials
+//       k_colfin(k)      partials -> ctx
+//       k_main<MID|LAST>(k)
+//   [all-reduce out]                      site-sharded runs only
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/phyloformer_amd.h"
+#include "pf_device.hip.h"
+
+using namespace pfk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---- RCCL, resolved lazily so the library loads without it --------------------------------
+struct PfNcclId { char internal[PF_UNIQUE_ID_BYTES]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, PfNcclId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+bool load_rccl(std::string& err) {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, PfNcclId, int)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(
+        dlsym(lib, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        err = "librccl is missing required symbols";
+        return false;
+    }
+    g_rccl.lib = lib;
+    return true;
+}
+constexpr int NCCL_FLOAT = 7, NCCL_SUM = 0;
+
+// ---- bf16 helpers (host) --------------------------------------------------------------------
+uint16_t f2bf(float f) {  // round to nearest even
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return uint16_t(u >> 16);
+}
+float bf2f(uint16_t b) {
+    uint32_t u = uint32_t(b) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+int kmap_h(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// Pack W[M][K] (row-major fp32) into MFMA A fragments, hi/lo split:
+//   out[((T * (K/16) + s) * 2 + hl) * 64 + lane][i] = W[32T + (lane & 31)][kmap(8s + i, lane >> 5)]
+// (rows >= M are zero).  K order matches the lane ownership of the B operand.
+void pack_frags(const float* W, int M, int K, int Mpad, uint16_t* out) {
+    const int nT = Mpad / 32, nS = K / 16;
+    for (int T = 0; T < nT; ++T)
+        for (int s = 0; s < nS; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int m = 32 * T + (lane & 31), k = kmap_h(8 * s + i, lane >> 5);
+                    const float w = (m < M) ? W[(size_t)m * K + k] : 0.f;
+                    const uint16_t hi = f2bf(w);
+                    const uint16_t lo = f2bf(w - bf2f(hi));
+                    const size_t base = ((size_t)(T * nS + s) * 2) * 64;
+                    out[(base + lane) * 8 + i] = hi;
+                    out[(base + 64 + lane) * 8 + i] = lo;
+                }
+}
+
+struct BlockDev {
+    float* wimg = nullptr;     // LDS image: FRAG_END frags (as bytes) ; stored as raw
+    float* consts = nullptr;   // CONST_LEN
+    float* rvqk = nullptr;     // RVQK_FRAGS frags for THIS block's row attention
+    float* bqk_row = nullptr;  // (host copy lives in consts of the previous stage)
+    float* row_woT = nullptr;  // [64][64]
+    float* row_bv = nullptr;   // [64]
+    float* row_bo = nullptr;   // [64]
+    float* col_wqk = nullptr;  // [8][64]
+    float* col_bqk = nullptr;  // [8]
+    float* col_wvT = nullptr;  // [64][64]
+    float* col_bv = nullptr;   // [64]
+};
+
+struct ProfSlot { int kid; hipEvent_t a, b; };
+const char* const KNAMES[] = {"embed", "rowfin", "colstats", "colfin", "main", "allreduce"};
+enum { K_EMBED = 0, K_ROWFIN, K_COLSTATS, K_COLFIN, K_MAIN, K_ALLREDUCE, K_COUNT };
+
+}  // namespace
+
+struct pf_handle {
+    int device = 0;
+    int n_blocks = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+    // options
+    int64_t max_seqs = 200;
+    bool profile = false;
+    bool debug_keep = false;
+    int64_t ws_limit_bytes = (int64_t)24 << 30;  // per-chunk workspace budget
+    // weights
+    float* table = nullptr;       // [22][64]
+    float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
+    std::vector<BlockDev> blk;
+    std::vector<void*> owned;     // every device allocation made at create
+    // pair index tables
+    int pair_n = -1;
+    int16_t* pair_i = nullptr;
+    int16_t* pair_j = nullptr;
+    // workspace
+    size_t ws_bytes = 0;
+    char* ws = nullptr;
+    uint8_t* d_idx = nullptr; size_t d_idx_bytes = 0;
+    float* d_out = nullptr; size_t d_out_bytes = 0;
+    // comm
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    // profiling
+    std::vector<ProfSlot> pending;
+    std::vector<hipEvent_t> free_events;
+    int64_t prof_n[K_COUNT] = {0};
+    double prof_ms[K_COUNT] = {0};
+    // debug taps
+    std::map<std::string, std::vector<float>> taps;
+};
+
+namespace {
+
+int fail(pf_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                 \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail((h), e_ == hipErrorOutOfMemory ? PF_ENOMEM : PF_EHIP, "%s: %s", \
+                        #call, hipGetErrorString(e_));                                  \
+    } while (0)
+
+template <typename T>
+int upload(pf_handle* h, const std::vector<T>& v, float** out) {
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, v.size() * sizeof(T)));
+    h->owned.push_back(p);
+    HIPCHK(h, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<float*>(p);
+    return PF_OK;
+}
+
+// view into the flat blob following weights.py::blob_layout
+struct Blob {
+    const float* p;
+    const float* take(size_t n) { const float* r = p; p += n; return r; }
+};
+
+struct AttnHost {
+    const float *g, *b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+};
+AttnHost take_attn(Blob& bl) {
+    AttnHost a;
+    a.g = bl.take(E); a.b = bl.take(E);
+    a.wq = bl.take(NH * E); a.bq = bl.take(NH);
+    a.wk = bl.take(NH * E); a.bk = bl.take(NH);
+    a.wv = bl.take(E * E); a.bv = bl.take(E);
+    a.wo = bl.take(E * E); a.bo = bl.take(E);
+    return a;
+}
+
+// fold the LayerNorm affine into a projection: W' = W diag(g), b' = b + W beta  (double accumulate)
+void fold(const float* W, const float* bias, const float* g, const float* beta, int M, int K,
+          std::vector<float>& Wf, std::vector<float>& bf) {
+    Wf.resize((size_t)M * K);
+    bf.resize(M);
+    for (int m = 0; m < M; ++m) {
+        double acc = bias ? bias[m] : 0.0;
+        for (int k = 0; k < K; ++k) {
+            Wf[(size_t)m * K + k] = (float)((double)W[(size_t)m * K + k] * (double)g[k]);
+            acc += (double)W[(size_t)m * K + k] * (double)beta[k];
+        }
+        bf[m] = (float)acc;
+    }
+}
+
+int prepare_weights(pf_handle* h, const pf_weights_t* w) {
+    Blob bl{w->blob};
+    const float* emb_w = bl.take((size_t)E * NA);
+    const float* emb_b = bl.take(E);
+    std::vector<float> table((size_t)NA * E);
+    for (int a = 0; a < NA; ++a)
+        for (int c = 0; c < E; ++c) {
+            // conv on a one-hot = W[c][a] + b[c] (model.py:139-141), then ReLU (:142)
+            const float v = emb_w[c * NA + a] + emb_b[c];
+            table[(size_t)a * E + c] = v > 0.f ? v : 0.f;
+        }
+    int rc = upload(h, table, &h->table);
+    if (rc) return rc;
+
+    const int nb = w->n_blocks;
+    h->blk.resize(nb);
+    std::vector<AttnHost> rows(nb), cols(nb);
+    struct FfnHost { const float *g, *b, *w1, *b1, *w2, *b2; };
+    std::vector<FfnHost> ffn(nb);
+    for (int k = 0; k < nb; ++k) {
+        rows[k] = take_attn(bl);
+        cols[k] = take_attn(bl);
+        ffn[k].g = bl.take(E); ffn[k].b = bl.take(E);
+        ffn[k].w1 = bl.take((size_t)FF * E); ffn[k].b1 = bl.take(FF);
+        ffn[k].w2 = bl.take((size_t)E * FF); ffn[k].b2 = bl.take(E);
+    }
+    const float* head_w = bl.take(E);
+    const float* head_b = bl.take(1);
+    if ((uint64_t)(bl.p - w->blob) != w->blob_len)
+        return fail(h, PF_EINVAL, "weight blob has %llu floats, expected %llu",
+                    (unsigned long long)w->blob_len, (unsigned long long)(bl.p - w->blob));
+
+    std::vector<std::vector<float>> row_bqk(nb);
+    for (int k = 0; k < nb; ++k) {
+        BlockDev& d = h->blk[k];
+        const AttnHost& r = rows[k];
+        const AttnHost& c = cols[k];
+        // ---- row attention of block k
+        std::vector<float> wq, bq, wk, bk, wv, bv;
+        fold(r.wq, r.bq, r.g, r.b, NH, E, wq, bq);
+        fold(r.wk, r.bk, r.g, r.b, NH, E, wk, bk);
+        fold(r.wv, r.bv, r.g, r.b, E, E, wv, bv);
+        std::vector<float> vqk((size_t)72 * E);
+        std::copy(wv.begin(), wv.end(), vqk.begin());
+        std::copy(wq.begin(), wq.end(), vqk.begin() + 64 * E);
+        std::copy(wk.begin(), wk.end(), vqk.begin() + 68 * E);
+        std::vector<uint16_t> rv((size_t)RVQK_FRAGS * 8);
+        pack_frags(vqk.data(), 72, E, 96, rv.data());
+        if ((rc = upload(h, rv, &d.rvqk))) return rc;
+        row_bqk[k].assign(8, 0.f);
+        for (int i = 0; i < 4; ++i) { row_bqk[k][i] = bq[i]; row_bqk[k][4 + i] = bk[i]; }
+        std::vector<float> woT((size_t)E * E);
+        for (int cc = 0; cc < E; ++cc)
+            for (int hd = 0; hd < E; ++hd) woT[(size_t)hd * E + cc] = r.wo[(size_t)cc * E + hd];
+        if ((rc = upload(h, woT, &d.row_woT))) return rc;
+        if ((rc = upload(h, bv, &d.row_bv))) return rc;
+        if ((rc = upload(h, std::vector<float>(r.bo, r.bo + E), &d.row_bo))) return rc;
+        // ---- column attention of block k
+        std::vector<float> cwq, cbq, cwk, cbk, cwv, cbv;
+        fold(c.wq, c.bq, c.g, c.b, NH, E, cwq, cbq);
+        fold(c.wk, c.bk, c.g, c.b, NH, E, cwk, cbk);
+        fold(c.wv, c.bv, c.g, c.b, E, E, cwv, cbv);
+        std::vector<float> wqk((size_t)8 * E), bqk(8);
+        std::copy(cwq.begin(), cwq.end(), wqk.begin());
+        std::copy(cwk.begin(), cwk.end(), wqk.begin() + 4 * E);
+        for (int i = 0; i < 4; ++i) { bqk[i] = cbq[i]; bqk[4 + i] = cbk[i]; }
+        if ((rc = upload(h, wqk, &d.col_wqk))) return rc;
+        if ((rc = upload(h, bqk, &d.col_bqk))) return rc;
+        std::vector<float> wvT((size_t)E * E);
+        for (int hd = 0; hd < E; ++hd)
+            for (int cc = 0; cc < E; ++cc) wvT[(size_t)cc * E + hd] = cwv[(size_t)hd * E + cc];
+        if ((rc = upload(h, wvT, &d.col_wvT))) return rc;
+        if ((rc = upload(h, cbv, &d.col_bv))) return rc;
+    }
+    for (int k = 0; k < nb; ++k) {
+        BlockDev& d = h->blk[k];
+        // ---- LDS image of k_main(k): FFN + column out_proj
+        std::vector<float> w1f, b1f;
+        fold(ffn[k].w1, ffn[k].b1, ffn[k].g, ffn[k].b, FF, E, w1f, b1f);
+        std::vector<uint16_t> img((size_t)FRAG_END * 8);
+        pack_frags(w1f.data(), FF, E, FF, img.data() + (size_t)FRAG_W1 * 8);
+        pack_frags(ffn[k].w2, E, FF, E, img.data() + (size_t)FRAG_W2 * 8);
+        pack_frags(cols[k].wo, E, E, E, img.data() + (size_t)FRAG_WO * 8);
+        if ((rc = upload(h, img, &d.wimg))) return rc;
+        std::vector<float> cst(CONST_LEN, 0.f);
+        std::copy(b1f.begin(), b1f.end(), cst.begin() + CONST_B1);
+        std::copy(ffn[k].b2, ffn[k].b2 + E, cst.begin() + CONST_B2);
+        if (k + 1 < nb) std::copy(row_bqk[k + 1].begin(), row_bqk[k + 1].end(), cst.begin() + CONST_BQK);
+        std::copy(head_w, head_w + E, cst.begin() + CONST_HW);
+        cst[CONST_HB] = head_b[0];
+        std::copy(cols[k].bo, cols[k].bo + E, cst.begin() + CONST_BOC);
+        if ((rc = upload(h, cst, &d.consts))) return rc;
+    }
+    std::vector<float> cst0(CONST_LEN, 0.f);
+    std::copy(row_bqk[0].begin(), row_bqk[0].end(), cst0.begin() + CONST_BQK);
+    return upload(h, cst0, &h->first_consts);
+}
+
+int ensure_pairs(pf_handle* h, int N) {
+    if (h->pair_n == N) return PF_OK;
+    const int P = N * (N - 1) / 2;
+    std::vector<int16_t> pi(P), pj(P);
+    int k = 0;
+    for (int i = 0; i < N; ++i)  // model.py:13-17
+        for (int j = i + 1; j < N; ++j) { pi[k] = (int16_t)i; pj[k] = (int16_t)j; ++k; }
+    if (h->pair_i) { hipFree(h->pair_i); hipFree(h->pair_j); h->pair_i = h->pair_j = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->pair_i, P * sizeof(int16_t)));
+    HIPCHK(h, hipMalloc((void**)&h->pair_j, P * sizeof(int16_t)));
+    HIPCHK(h, hipMemcpyAsync(h->pair_i, pi.data(), P * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pair_j, pj.data(), P * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->pair_n = N;
+    return PF_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx;
+    int G;
+};
+
+int colstats_groups(int B, int P, int Lloc) {
+    const int chunks = (Lloc + 3) / 4;
+    int G = (1024 + B * chunks - 1) / (B * chunks);
+    G = std::min(G, std::max(1, P / 32));
+    return std::max(1, std::min(G, 32));
+}
+
+size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[8]) {
+    const size_t tok = (size_t)B * P * Lloc;
+    size_t o = 0;
+    off[0] = o; o = align_up(o + tok * 64 * 4, 256);                     // x
+    off[1] = o; o = align_up(o + tok * 4 * 4, 256);                      // qrow
+    off[2] = o; o = align_up(o + tok * 4 * 4, 256);                      // qcol
+    off[3] = o; o = align_up(o + (size_t)B * P * SROW * 4, 256);         // srow
+    off[4] = o; o = align_up(o + (size_t)B * P * MROW * 4, 256);         // mrow
+    off[5] = o; o = align_up(o + (size_t)B * G * Lloc * CPART * 4, 256); // part
+    off[6] = o; o = align_up(o + (size_t)B * Lloc * 64 * 4, 256);        // ctx
+    return o;
+}
+
+int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w) {
+    size_t off[8];
+    w->G = colstats_groups(B, P, Lloc);
+    const size_t need = workspace_bytes(B, P, Lloc, w->G, off);
+    if (need > h->ws_bytes) {
+        if (h->ws) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
+        HIPCHK(h, hipMalloc((void**)&h->ws, need));
+        h->ws_bytes = need;
+    }
+    w->x = (float*)(h->ws + off[0]); w->qrow = (float*)(h->ws + off[1]);
+    w->qcol = (float*)(h->ws + off[2]); w->srow = (float*)(h->ws + off[3]);
+    w->mrow = (float*)(h->ws + off[4]); w->part = (float*)(h->ws + off[5]);
+    w->ctx = (float*)(h->ws + off[6]);
+    return PF_OK;
+}
+
+hipEvent_t get_event(pf_handle* h) {
+    if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    pf_handle* h; int kid; hipEvent_t a{}, b{};
+    ProfScope(pf_handle* h_, int kid_) : h(h_), kid(kid_) {
+        if (h->profile) { a = get_event(h); b = get_event(h); hipEventRecord(a, h->stream); }
+    }
+    ~ProfScope() {
+        if (h->profile) { hipEventRecord(b, h->stream); h->pending.push_back({kid, a, b}); }
+    }
+};
+void drain_profile(pf_handle* h) {
+    if (h->pending.empty()) return;
+    hipStreamSynchronize(h->stream);
+    for (auto& s : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h->prof_n[s.kid]++; h->prof_ms[s.kid] += ms; }
+        h->free_events.push_back(s.a);
+        h->free_events.push_back(s.b);
+    }
+    h->pending.clear();
+}
+
+int save_tap(pf_handle* h, const std::string& name, const float* dptr, size_t n) {
+    std::vector<float>& v = h->taps[name];
+    v.resize(n);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(v.data(), dptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PF_OK;
+}
+
+int allreduce(pf_handle* h, float* buf, size_t count) {
+    if (h->world <= 1) return PF_OK;
+    if (!h->comm) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
+    ProfScope ps(h, K_ALLREDUCE);
+    int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, h->comm, h->stream);
+    if (rc != 0)
+        return fail(h, PF_ERCCL, "ncclAllReduce failed: %s",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return PF_OK;
+}
+
+template <int MODE>
+int launch_main(pf_handle* h, const MainArgs& a, int kid) {
+    static bool attr_set[16] = {false};
+    if (!attr_set[h->device & 15]) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_main<MODE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES));
+        attr_set[h->device & 15] = true;
+    }
+    const int ntasks = a.B * a.P;
+    const int grid = std::max(1, std::min(h->prop.multiProcessorCount, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
+    ProfScope ps(h, kid);
+    hipLaunchKernelGGL(k_main<MODE>, dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    return PF_OK;
+}
+
+// one batch chunk, everything resident on the device
+int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, int L_total, float* d_out) {
+    const int P = N * (N - 1) / 2;
+    Workspace w;
+    int rc = ensure_workspace(h, B, P, Lloc, &w);
+    if (rc) return rc;
+    if ((rc = ensure_pairs(h, N))) return rc;
+    const int nb = h->n_blocks;
+
+    MainArgs m{};
+    m.x = w.x; m.qrow = w.qrow; m.qcol = w.qcol; m.mrow = w.mrow; m.ctx = w.ctx; m.srow = w.srow;
+    m.out = d_out; m.table = h->table; m.idx = d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
+    m.B = B; m.N = N; m.P = P; m.Lloc = Lloc; m.inv_L_total = 1.0f / (float)L_total;
+    m.store_x_last = h->debug_keep ? 1 : 0;
+
+    m.wimg = nullptr; m.consts = h->first_consts;
+    m.rvqk = reinterpret_cast<const bf16x8*>(h->blk[0].rvqk);
+    if ((rc = launch_main<MODE_FIRST>(h, m, K_EMBED))) return rc;
+    const size_t ntok = (size_t)B * P * Lloc;
+    if (h->debug_keep && (rc = save_tap(h, "x0", w.x, ntok * 64))) return rc;
+
+    for (int k = 0; k < nb; ++k) {
+        const BlockDev& d = h->blk[k];
+        if ((rc = allreduce(h, w.srow, (size_t)B * P * SROW))) return rc;
+        if (h->debug_keep && (rc = save_tap(h, "srow" + std::to_string(k), w.srow, (size_t)B * P * SROW))) return rc;
+        {
+            RowFinArgs a{w.srow, w.mrow, d.row_woT, d.row_bv, d.row_bo, B * P, (float)L_total};
+            ProfScope ps(h, K_ROWFIN);
+            hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
+            HIPCHK(h, hipGetLastError());
+        }
+        {
+            ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 3) / 4};
+            ProfScope ps(h, K_COLSTATS);
+            hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+            HIPCHK(h, hipGetLastError());
+        }
+        {
+            ColFinArgs a{w.part, w.ctx, d.col_wvT, d.col_bv, B, Lloc, w.G, (float)P};
+            ProfScope ps(h, K_COLFIN);
+            hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(256), 0, h->stream, a);
+            HIPCHK(h, hipGetLastError());
+        }
+        if (h->debug_keep) {
+            if ((rc = save_tap(h, "ctx" + std::to_string(k), w.ctx, (size_t)B * Lloc * 64))) return rc;
+            if ((rc = save_tap(h, "mrow" + std::to_string(k), w.mrow, (size_t)B * P * MROW))) return rc;
+        }
+        m.wimg = reinterpret_cast<const bf16x8*>(d.wimg);
+        m.consts = d.consts;
+        if (k + 1 < nb) {
+            m.rvqk = reinterpret_cast<const bf16x8*>(h->blk[k + 1].rvqk);
+            if ((rc = launch_main<MODE_MID>(h, m, K_MAIN))) return rc;
+        } else {
+            m.rvqk = nullptr;
+            if ((rc = launch_main<MODE_LAST>(h, m, K_MAIN))) return rc;
+        }
+        if (h->debug_keep && (rc = save_tap(h, "x" + std::to_string(k + 1), w.x, ntok * 64))) return rc;
+    }
+    return allreduce(h, d_out, (size_t)B * P);
+}
+
+int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
+    if (!h) return PF_EINVAL;
+    if (B < 1 || N < 2 || Lloc < 1 || L_total < Lloc)
+        return fail(h, PF_EINVAL, "bad dimensions B=%d N=%d L=%d (L_total=%d)", B, N, Lloc, L_total);
+    if (h->max_seqs > 0 && N > h->max_seqs)
+        // same condition and wording as adaptable_seq2pair, phyloformer/model.py:24-28
+        return fail(h, PF_EINVAL, "n_seqs must be smaller or equal to %lld (or pre-compute a larger global_seq2pair)",
+                    (long long)h->max_seqs);
+    if (N > 32767) return fail(h, PF_EINVAL, "n_seqs %d exceeds the pair-table index range", N);
+    return PF_OK;
+}
+
+int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
+    size_t off[8];
+    const size_t per = workspace_bytes(1, P, Lloc, 32, off);
+    int64_t nb = h->ws_limit_bytes / (int64_t)std::max<size_t>(per, 1);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(B, nb));
+}
+
+int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_begin, int l_end,
+                        int L_total, float* d_out) {
+    const int Lloc = l_end - l_begin;
+    int rc = check_dims(h, B, N, Lloc, L_total);
+    if (rc) return rc;
+    if (l_begin < 0 || l_end > L_total) return fail(h, PF_EINVAL, "site range [%d, %d) outside [0, %d)", l_begin, l_end, L_total);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int P = N * (N - 1) / 2;
+    const int cb = chunk_batch(h, B, P, Lloc);
+    for (int b0 = 0; b0 < B; b0 += cb) {
+        const int nbch = std::min(cb, B - b0);
+        rc = forward_chunk(h, d_idx + (size_t)b0 * N * Lloc, nbch, N, Lloc, L_total, d_out + (size_t)b0 * P);
+        if (rc) return rc;
+    }
+    return PF_OK;
+}
+
+int forward_host_impl(pf_handle* h, const uint8_t* idx, int B, int N, int l_begin, int l_end,
+                      int L_total, float* out) {
+    const int Lloc = l_end - l_begin;
+    int rc = check_dims(h, B, N, Lloc, L_total);
+    if (rc) return rc;
+    if (!idx || !out) return fail(h, PF_EINVAL, "null buffer");
+    const size_t nidx = (size_t)B * N * Lloc;
+    for (size_t i = 0; i < nidx; ++i)
+        if (idx[i] >= NA) return fail(h, PF_EINVAL, "residue index %d at offset %zu is outside 0..21", (int)idx[i], i);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int P = N * (N - 1) / 2;
+    if (nidx > h->d_idx_bytes) {
+        if (h->d_idx) hipFree(h->d_idx);
+        h->d_idx = nullptr; h->d_idx_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_idx, nidx));
+        h->d_idx_bytes = nidx;
+    }
+    const size_t nout = (size_t)B * P * sizeof(float);
+    if (nout > h->d_out_bytes) {
+        if (h->d_out) hipFree(h->d_out);
+        h->d_out = nullptr; h->d_out_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_out, nout));
+        h->d_out_bytes = nout;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, idx, nidx, hipMemcpyHostToDevice, h->stream));
+    rc = forward_device_impl(h, h->d_idx, B, N, l_begin, l_end, L_total, h->d_out);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_out, nout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_abi_version(void) { return PF_ABI_VERSION; }
+
+uint64_t pf_blob_len(int32_t n_blocks, int32_t n_heads, int32_t embed_dim) {
+    const uint64_t Ed = embed_dim, Hd = n_heads;
+    const uint64_t attn = 2 * Ed + 2 * (Hd * Ed + Hd) + 2 * (Ed * Ed + Ed);
+    const uint64_t ffn = 2 * Ed + (4 * Ed * Ed + 4 * Ed) + (4 * Ed * Ed + Ed);
+    return Ed * NA + Ed + (uint64_t)n_blocks * (2 * attn + ffn) + Ed + 1;
+}
+
+int pf_create(const pf_weights_t* w, int device, pf_handle_t** out) {
+    if (!w || !out || !w->blob) return fail(nullptr, PF_EINVAL, "null argument");
+    *out = nullptr;
+    if (w->embed_dim != E || w->n_heads != NH || w->n_alphabet != NA || w->n_blocks < 1 || w->n_blocks > 64)
+        return fail(nullptr, PF_EINVAL,
+                    "unsupported architecture: n_blocks=%d n_heads=%d embed_dim=%d n_alphabet=%d "
+                    "(kernels are specialised for n_heads=4, embed_dim=64, n_alphabet=22)",
+                    w->n_blocks, w->n_heads, w->embed_dim, w->n_alphabet);
+    if (w->blob_len != pf_blob_len(w->n_blocks, w->n_heads, w->embed_dim))
+        return fail(nullptr, PF_EINVAL, "weight blob has %llu floats, expected %llu",
+                    (unsigned long long)w->blob_len,
+                    (unsigned long long)pf_blob_len(w->n_blocks, w->n_heads, w->embed_dim));
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, PF_EHIP, "no HIP device available (%s); there is no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, PF_EINVAL, "device %d out of range (have %d)", device, ndev);
+    pf_handle* h = new pf_handle();
+    h->device = device;
+    h->n_blocks = w->n_blocks;
+    int rc = PF_OK;
+    do {
+        if ((e = hipSetDevice(device)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); break; }
+        if ((e = hipGetDeviceProperties(&h->prop, device)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); break; }
+        if (std::string(h->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+            rc = fail(nullptr, PF_EHIP, "device %d is %s; this library is built for gfx950 only", device, h->prop.gcnArchName);
+            break;
+        }
+        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        rc = prepare_weights(h, w);
+        if (rc) g_create_error = h->err;
+    } while (0);
+    if (rc) { pf_destroy(h); return rc; }
+    *out = h;
+    return PF_OK;
+}
+
+int pf_destroy(pf_handle_t* h) {
+    if (!h) return PF_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (auto& s : h->pending) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto e : h->free_events) hipEventDestroy(e);
+    for (void* p : h->owned) hipFree(p);
+    if (h->pair_i) hipFree(h->pair_i);
+    if (h->pair_j) hipFree(h->pair_j);
+    if (h->ws) hipFree(h->ws);
+    if (h->d_idx) hipFree(h->d_idx);
+    if (h->d_out) hipFree(h->d_out);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return PF_OK;
+}
+
+const char* pf_last_error(const pf_handle_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
+    if (!h || !key) return PF_EINVAL;
+    const std::string k(key);
+    if (k == "max_seqs") h->max_seqs = value;
+    else if (k == "profile") { drain_profile(h); h->profile = value != 0; }
+    else if (k == "debug_keep") h->debug_keep = value != 0;
+    else if (k == "ws_limit_mb") h->ws_limit_bytes = value << 20;
+    else return fail(h, PF_EINVAL, "unknown option '%s'", key);
+    return PF_OK;
+}
+
+int pf_forward(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t L, float* out) {
+    if (!h) return PF_EINVAL;
+    return forward_host_impl(h, idx, B, N, 0, L, L, out);
+}
+
+int pf_forward_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N, int32_t L, float* d_out) {
+    if (!h) return PF_EINVAL;
+    return forward_device_impl(h, d_idx, B, N, 0, L, L, d_out);
+}
+
+int pf_forward_sharded(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t l_begin,
+                       int32_t l_end, int32_t L_total, float* out) {
+    if (!h) return PF_EINVAL;
+    return forward_host_impl(h, idx, B, N, l_begin, l_end, L_total, out);
+}
+
+int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N, int32_t l_begin,
+                              int32_t l_end, int32_t L_total, float* d_out) {
+    if (!h) return PF_EINVAL;
+    return forward_device_impl(h, d_idx, B, N, l_begin, l_end, L_total, d_out);
+}
+
+int pf_comm_unique_id(void* id_out) {
+    std::string err;
+    if (!id_out) return PF_EINVAL;
+    if (!load_rccl(err)) return fail(nullptr, PF_ERCCL, "%s", err.c_str());
+    int rc = g_rccl.GetUniqueId(id_out);
+    if (rc != 0) return fail(nullptr, PF_ERCCL, "ncclGetUniqueId failed (%d)", rc);
+    return PF_OK;
+}
+
+int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t world_size) {
+    if (!h || world_size < 1 || rank < 0 || rank >= world_size) return PF_EINVAL;
+    if (h->comm) return fail(h, PF_ESTATE, "communicator already initialised");
+    h->rank = rank;
+    h->world = world_size;
+    if (world_size == 1) return PF_OK;
+    if (!unique_id) return fail(h, PF_EINVAL, "null unique id");
+    std::string err;
+    if (!load_rccl(err)) return fail(h, PF_ERCCL, "%s", err.c_str());
+    HIPCHK(h, hipSetDevice(h->device));
+    PfNcclId id;
+    std::memcpy(id.internal, unique_id, PF_UNIQUE_ID_BYTES);
+    int rc = g_rccl.CommInitRank(&h->comm, world_size, id, rank);
+    if (rc != 0) {
+        h->comm = nullptr;
+        return fail(h, PF_ERCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    }
+    return PF_OK;
+}
+
+int pf_comm_destroy(pf_handle_t* h) {
+    if (!h) return PF_EINVAL;
+    if (h->comm) { hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    h->world = 1; h->rank = 0;
+    return PF_OK;
+}
+
+int pf_synchronize(pf_handle_t* h) {
+    if (!h) return PF_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_get_stream(pf_handle_t* h, void** s) {
+    if (!h || !s) return PF_EINVAL;
+    *s = (void*)h->stream;
+    return PF_OK;
+}
+
+int pf_device_malloc(pf_handle_t* h, size_t bytes, void** out) {
+    if (!h || !out) return PF_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMalloc(out, bytes ? bytes : 1));
+    return PF_OK;
+}
+int pf_device_free(pf_handle_t* h, void* p) {
+    if (!h) return PF_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(p));
+    return PF_OK;
+}
+int pf_memcpy_h2d(pf_handle_t* h, void* dst, const void* src, size_t bytes) {
+    if (!h) return PF_EINVAL;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+int pf_memcpy_d2h(pf_handle_t* h, void* dst, const void* src, size_t bytes) {
+    if (!h) return PF_EINVAL;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_profile_reset(pf_handle_t* h) {
+    if (!h) return PF_EINVAL;
+    drain_profile(h);
+    for (int i = 0; i < K_COUNT; ++i) { h->prof_n[i] = 0; h->prof_ms[i] = 0; }
+    return PF_OK;
+}
+
+int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double* total_ms) {
+    if (!h || !kernel) return PF_EINVAL;
+    drain_profile(h);
+    for (int i = 0; i < K_COUNT; ++i)
+        if (std::strcmp(kernel, KNAMES[i]) == 0) {
+            if (launches) *launches = h->prof_n[i];
+            if (total_ms) *total_ms = h->prof_ms[i];
+            return PF_OK;
+        }
+    return fail(h, PF_EINVAL, "unknown kernel '%s'", kernel);
+}
+
+int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap) {
+    if (!h || !name) return PF_EINVAL;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return fail(h, PF_ESTATE, "no tap '%s' (set debug_keep=1 and run a forward)", name);
+    const int64_t n = (int64_t)it->second.size();
+    if (dst) std::memcpy(dst, it->second.data(), (size_t)std::min(n, cap) * sizeof(float));
+    return n;
+}
+
+int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes) {
+    if (!h) return PF_EINVAL;
+    if (name_out && name_cap) snprintf(name_out, name_cap, "%s (%s)", h->prop.name, h->prop.gcnArchName);
+    if (cu_count) *cu_count = h->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = h->prop.totalGlobalMem;
+    return PF_OK;
+}
+
+// Hardware-layout self test (see k_selftest); out must hold 2304 floats.
+int pf_selftest(pf_handle_t* h, float* out) {
+    if (!h || !out) return PF_EINVAL;
+    float* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, 2304 * sizeof(float)));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, h->stream, d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d, 2304 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(d);
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""Host-side mirror of the reference's Python boundary: FASTA, PHYLIP, .ckpt, blob, NJ, sharding."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from phyloformer_amd import ckpt, fasta, phylip, weights as W
+from phyloformer_amd.dist import alignment_range, site_range, site_ranges
+from phyloformer_amd.nj import neighbor_joining
+
+CKPTS = ["pf", "pf_base", "pf_indel", "pf_cherry", "pf_selreg"]
+
+
+# ---- FASTA (reference: phyloformer/data.py:11-31) --------------------------------------------
+def test_fasta_reference_msa(repo):
+    idx, ids = fasta.load_alignment(os.path.join(repo, "data/testdata/msas/0_20_tips.fa"))
+    assert idx.shape == (20, 250) and idx.dtype == np.uint8
+    assert ids[0] == "T4" and len(ids) == 20          # trailing blanks of the header are stripped
+    assert idx.max() < 20                             # test MSAs have no X / gap
+
+
+def test_fasta_rules():
+    idx, ids = fasta.parse_fasta(b">a \nAR\nND\n\n> b\nX-\n  CQ  \n")
+    assert ids == ["a", " b"]                         # line.strip() then line[1:], data.py:21-22
+    assert idx.tolist() == [[0, 1, 2, 3], [20, 21, 4, 5]]
+    with pytest.raises(KeyError):                     # LOOKUP[char], data.py:26
+        fasta.parse_fasta(b">a\nAZB\n")
+    with pytest.raises(KeyError):
+        fasta.parse_fasta(b">a\nar\n")                # lower case is not in the alphabet
+    with pytest.raises(ValueError):                   # ragged → torch.tensor fails, data.py:28
+        fasta.parse_fasta(b">a\nAR\n>b\nA\n")
+    with pytest.raises(IndexError):
+        fasta.parse_fasta(b"AR\n>a\nAR\n")
+
+
+def test_one_hot_round_trip():
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, 22, size=(5, 9)).astype(np.uint8)
+    oh = fasta.one_hot(idx)
+    assert oh.shape == (22, 9, 5) and oh.dtype == np.int64 and (oh.sum(0) == 1).all()
+    assert np.array_equal(fasta.from_one_hot(oh[None].astype(np.float32))[0], idx)
+
+
+# ---- PHYLIP (reference: infer_alns.py:14-25) --------------------------------------------------
+def test_phylip_text_matches_reference_cli(repo, golden):
+    g = golden("e2e_testdata.npz")
+    _idx, ids = fasta.load_alignment(os.path.join(repo, "data/testdata/msas/0_20_tips.fa"))
+    dm, text = phylip.vec_to_phylip(g["pf_base/0_20_tips"], ids)
+    with open(os.path.join(repo, "tests/golden/0_20_tips.pf_base.phy")) as fh:
+        assert text == fh.read()                      # byte-identical to the reference CLI's file
+    assert dm.shape == (20, 20) and np.array_equal(dm, dm.T) and (np.diag(dm) == 0).all()
+    assert text.splitlines()[1].startswith("T4 0.0000000000 0.3387762010")
+
+
+def test_phylip_pair_order():
+    d = np.arange(1, 7, dtype=np.float32)
+    dm = phylip.vec_to_matrix(d, 4)
+    assert dm[0].tolist() == [0, 1, 2, 3] and dm[1, 2:].tolist() == [4, 5] and dm[2, 3] == 6
+    assert phylip.vec_to_matrix(np.float32(2.5), 2).tolist() == [[0, 2.5], [2.5, 0]]
+
+
+# ---- checkpoints (reference: infer_alns.py:71-82) ----------------------------------------------
+@pytest.mark.parametrize("name", CKPTS)
+def test_ckpt_reader_matches_torch_load(repo, name):
+    torch = pytest.importorskip("torch")
+    path = os.path.join(repo, "models", f"{name}.ckpt")
+    sd, hp = ckpt.load_state_dict(path)
+    ref = torch.load(path, map_location="cpu", weights_only=True)
+    assert hp == ref["hyper_parameters"] == {"nb_blocks": 6, "nb_heads": 4, "embed_dim": 64, "dropout": 0.0}
+    want = {k.replace("model.", ""): v for k, v in ref["state_dict"].items() if k != "model.seq2pair"}
+    assert set(sd) == set(want) and len(sd) == 160
+    for k, v in want.items():
+        assert np.array_equal(sd[k], v.numpy()), k
+    w = W.from_state_dict(sd)
+    assert (w.n_blocks, w.n_heads, w.embed_dim, w.n_params) == (6, 4, 64, 308449)
+
+
+def test_ckpt_refuses_code_and_garbage(tmp_path):
+    import pickle
+    import zipfile
+    p = tmp_path / "evil.ckpt"
+    with zipfile.ZipFile(p, "w") as z:
+        z.writestr("evil/data.pkl", pickle.dumps({"state_dict": {"a": os.system}}, protocol=2))
+        z.writestr("evil/byteorder", "little")
+    sd, _ = ckpt.load_state_dict(p)       # os.system decodes to an inert placeholder, never called
+    assert sd == {}
+    q = tmp_path / "garbage.ckpt"
+    q.write_bytes(b"not a zip")
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.load_ckpt(q)
+
+
+def test_weight_blob_layout(weights):
+    w = weights("pf")
+    blob = w.blob()
+    assert blob.dtype == np.float32 and blob.size == 308449
+    assert np.array_equal(blob[:64 * 22].reshape(64, 22), w["embedding_block.0.weight"])
+    assert blob[-1] == w["pwFNN.0.bias"][0]
+    bad = dict(w.tensors)
+    bad["attention_blocks.0.ffn.0.weight"] = np.zeros((128, 64), np.float32)
+    with pytest.raises(ckpt.CheckpointError):
+        W.from_state_dict(bad)
+
+
+# ---- C ABI: the library builds, loads and exports every declared symbol -------------------------
+def test_abi_symbols_exported(repo):
+    from phyloformer_amd import build, engine
+    build.build()
+    lib = engine.load_library()
+    header = open(os.path.join(repo, "include/phyloformer_amd.h")).read()
+    declared = set(re.findall(r"^(?:int64_t|uint64_t|int|const char\*)\s+(pf_\w+)\(", header, re.M))
+    assert declared and declared == set(engine.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pf_abi_version() == 1
+    assert lib.pf_blob_len(6, 4, 64) == 308449
+
+
+def test_no_cpu_fallback_without_gpu(weights):
+    """On a machine without a gfx950 device pf_create must fail loudly."""
+    import ctypes
+    from phyloformer_amd import engine
+    try:
+        ndev = ctypes.CDLL("libamdhip64.so").hipGetDeviceCount
+        n = ctypes.c_int(0)
+        has_gpu = ndev(ctypes.byref(n)) == 0 and n.value > 0
+    except OSError:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine.EngineError, match="no HIP device|no CPU fallback"):
+        engine.Engine(weights("pf"))
+
+
+# ---- sharding helpers / NJ ---------------------------------------------------------------------
+def test_site_and_alignment_ranges():
+    assert site_ranges(2000, 8) == [(250 * r, 250 * (r + 1)) for r in range(8)]
+    r = site_ranges(500, 8)
+    assert r[0] == (0, 63) and r[-1] == (441, 500) and sum(b - a for a, b in r) == 500
+    assert site_ranges(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert [alignment_range(10, 4, k) for k in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert site_range(7, 1, 0) == (0, 7)
+
+
+def test_neighbor_joining_recovers_additive_tree():
+    # ((a:1,b:2):1,(c:3,d:4):1): additive distances → NJ must return exactly these branch lengths
+    ids = ["a", "b", "c", "d"]
+    d = np.array([[0, 3, 6, 7], [3, 0, 7, 8], [6, 7, 0, 7], [7, 8, 7, 0]], float)
+    nwk = neighbor_joining(d, ids)
+    assert nwk.endswith(";\n") and all(t in nwk for t in ids)
+    lens = sorted(float(x) for x in re.findall(r":([0-9.eE+-]+)", nwk))
+    assert lens == [1.0, 2.0, 2.0, 3.0, 4.0]
