@@ -61,7 +61,7 @@ constexpr int CONST_LEN = 464;                                // floats
 constexpr int MAIN_LDS_BYTES = FRAG_END * 16 + CONST_LEN * 4; // 149,056 B
 constexpr int RVQK_FRAGS = 3 * 4 * 2 * 64;                    // next block's row [Wv';Wq';Wk'] frags
 
-constexpr int MAIN_THREADS = 256;  // 4 waves, one per SIMD, up to 512 VGPRs each
+constexpr int MAIN_THREADS = 512;  // 8 waves: two per SIMD so MFMA and VALU phases of different waves overlap
 constexpr int MAIN_WAVES = MAIN_THREADS / 64;
 
 __device__ __forceinline__ int kmap(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
@@ -95,10 +95,51 @@ __device__ __forceinline__ float half32_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// xor-shuffle inside each 32-lane half through the LDS crossbar (no LDS memory, no VALU slot)
+template <int MASK>
+__device__ __forceinline__ float swz_xor(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (MASK << 10) | 0x1f));
+}
+// Transposing reduction: every lane holds 32 partial values v[j]; afterwards lane t (of each half)
+// holds sum over the half's 32 lanes of v[t].  31 shuffles instead of 160 for 32 all-reduces, and
+// the running statistics need one register per lane instead of 32.
+template <int M>
+__device__ __forceinline__ void treduce_step(float* v, int t) {
+    const bool up = (t & M) != 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float send = up ? v[i] : v[i + M];
+        const float keep = up ? v[i + M] : v[i];
+        v[i] = keep + swz_xor<M>(send);
+    }
+}
+__device__ __forceinline__ float treduce32(float (&v)[32], int t) {
+    treduce_step<16>(v, t);
+    treduce_step<8>(v, t);
+    treduce_step<4>(v, t);
+    treduce_step<2>(v, t);
+    treduce_step<1>(v, t);
+    return v[0];
+}
+
 // ---- numerics ---------------------------------------------------------------------------
 __device__ __forceinline__ float elu1_acc(float v) { return v > 0.f ? v + 1.f : expf(v); }
 __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+}
+// Branch-free erf-GELU: gelu(x) = max(x,0) - 0.5|x| * poly(t) * exp(-x^2/2), t = 1/(1 + p|x|/sqrt2)
+// (Abramowitz & Stegun 7.1.26, |erf error| <= 1.5e-7 -> |gelu error| <= 5.3e-7 over all x, measured).
+// 12 VALU + v_rcp_f32 + v_exp_f32 instead of ocml erff's two divergent branches (~45 instructions).
+__device__ __forceinline__ float gelu_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);  // exp(-x^2/2)
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    return fmaf(-0.5f * ax, p * e, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
@@ -156,6 +197,8 @@ struct MainArgs {
     const int16_t* pair_j;  // [P]
     int B, N, P, Lloc;
     int store_x_last;       // debug: MODE_LAST also writes x back
+    int ablate;             // perf experiments only (results invalid): 1 no x load, 2 no stores,
+                            // 4 no next-row phase, 8 no apply phase, 16 no FFN
     float inv_L_total;
 };
 
@@ -168,7 +211,7 @@ enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
 //   MODE_MID  : row-apply + col-apply + FFN of block k;      -> row stats of block k+1
 //   MODE_LAST : row-apply + col-apply + FFN of the last block -> softplus head, site mean
 template <int MODE>
-__global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
+__global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bf16x8* lw = reinterpret_cast<const bf16x8*>(smem);
     const float* lc = reinterpret_cast<const float*>(smem + FRAG_END * 16);
@@ -212,9 +255,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
         int ai = 0, aj = 0;
         if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
 
-        float s_kv[32], s_q[4], s_k[4], s_out = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) s_kv[j] = 0.f;
+        // running row statistics: lane (t, h) owns S_kv[kmap(t, h)] (see treduce32)
+        float s_kv = 0.f, s_q[4], s_k[4], s_out = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s_q[i] = 0.f; s_k[i] = 0.f; }
 
@@ -239,13 +281,19 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
                 }
             } else {
                 const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tok * 64 + 4 * h);
+                if (a.ablate & 1) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    f32x4 u = xp[2 * g];
+                    for (int j = 0; j < 32; ++j) x[j] = 0.01f * (float)(j + t);
+                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] : 0.f;
+                    for (int g = 0; g < 8; ++g) {
+                        f32x4 u = xp[2 * g];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] : 0.f;
+                    }
                 }
                 // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
+                if (!(a.ablate & 8)) {
                 f32x16 ya[2];  // starts from the column out_proj bias
 #pragma unroll
                 for (int To = 0; To < 2; ++To) {
@@ -294,9 +342,10 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < 32; ++j) x[j] += ya[j >> 4][j & 15];
+                }
 
                 // ---- feed-forward (model.py:101-104): x += W2 gelu(W1' x~ + b1') + b2
-                {
+                if (!(a.ablate & 16)) {
                     float xn[32];
                     ln_pair(x, xn);
                     bf16x8 xb_hi[4], xb_lo[4];
@@ -330,7 +379,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
                         }
                         float gv[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) gv[r] = gelu_erf(ha[r]);
+                        for (int r = 0; r < 16; ++r) gv[r] = gelu_as(ha[r]);
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             bf16x8 g_hi, g_lo;
@@ -348,7 +397,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
                 }
             }
 
-            if (MODE != MODE_LAST) {
+            if (MODE != MODE_LAST && !(a.ablate & 4)) {
                 // ---- statistics of the next block's row attention (attention.py:163-190)
                 float xn[32];
                 ln_pair(x, xn);
@@ -380,11 +429,15 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
                     qn[i] = h ? ot[i] : qk[i];
                     kn[i] = h ? qk[i] : ot[i];
                 }
-                if (valid) {
+                {
+                    float kv[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) kv[j] = valid ? kn[j >> 3] * va[j >> 4][j & 15] : 0.f;
+                    s_kv += treduce32(kv, t);
+                }
+                if (valid && !(a.ablate & 2)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { s_q[i] += qn[i]; s_k[i] += kn[i]; }
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) s_kv[j] = fmaf(kn[j >> 3], va[j >> 4][j & 15], s_kv[j]);
                     if (h == 0) {
                         f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
                         *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = qs;
@@ -396,7 +449,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
                         xo[2 * g] = u;
                     }
                 }
-            } else {
+            } else if (MODE == MODE_LAST) {
                 // ---- head: softplus(w.x + b) summed over sites (model.py:182-185)
                 float z = 0.f;
 #pragma unroll
@@ -422,15 +475,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, 1) k_main(MainArgs a) {
         if (MODE != MODE_LAST) {
             float* sr = a.srow + (size_t)task * SROW;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) s_kv[j] = half32_sum(s_kv[j]);
-#pragma unroll
             for (int i = 0; i < 4; ++i) { s_q[i] = half32_sum(s_q[i]); s_k[i] = half32_sum(s_k[i]); }
+            sr[kmap(t, h)] = s_kv;
             if (t == 0) {
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    f32x4 u = {s_kv[4 * g], s_kv[4 * g + 1], s_kv[4 * g + 2], s_kv[4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(sr + 8 * g + 4 * h) = u;
-                }
                 if (h == 0) {
                     f32x4 u = {s_q[0], s_q[1], s_q[2], s_q[3]};
                     f32x4 w = {s_k[0], s_k[1], s_k[2], s_k[3]};

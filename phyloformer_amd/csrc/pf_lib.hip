@@ -137,6 +137,7 @@ struct pf_handle {
     int64_t max_seqs = 200;
     bool profile = false;
     bool debug_keep = false;
+    int ablate = 0;
     int64_t ws_limit_bytes = (int64_t)24 << 30;  // per-chunk workspace budget
     // weights
     float* table = nullptr;       // [22][64]
@@ -462,6 +463,7 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
     m.out = d_out; m.table = h->table; m.idx = d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
     m.B = B; m.N = N; m.P = P; m.Lloc = Lloc; m.inv_L_total = 1.0f / (float)L_total;
     m.store_x_last = h->debug_keep ? 1 : 0;
+    m.ablate = h->ablate;
 
     m.wimg = nullptr; m.consts = h->first_consts;
     m.rvqk = reinterpret_cast<const bf16x8*>(h->blk[0].rvqk);
@@ -654,6 +656,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     if (k == "max_seqs") h->max_seqs = value;
     else if (k == "profile") { drain_profile(h); h->profile = value != 0; }
     else if (k == "debug_keep") h->debug_keep = value != 0;
+    else if (k == "ablate") h->ablate = (int)value;
     else if (k == "ws_limit_mb") h->ws_limit_bytes = value << 20;
     else return fail(h, PF_EINVAL, "unknown option '%s'", key);
     return PF_OK;

@@ -1,0 +1,12 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import pf_oracle_torch as T
+from phyloformer_amd.weights import load_weights
+from phyloformer_amd.msa_sim import simulate_batch
+w = load_weights("models/pf.ckpt")
+idx = simulate_batch(1, 60, 500, seed=3)[0]
+for n in (16, 32, 64):
+    torch.set_num_threads(n)
+    T.forward(w.tensors, simulate_batch(1, 20, 100, seed=9)[0])
+    t0 = time.perf_counter(); T.forward(w.tensors, idx); print(n, "threads", round(time.perf_counter() - t0, 2), "s", flush=True)
