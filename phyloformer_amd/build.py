@@ -40,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", *SOURCES, "-o", LIB + ".tmp", "-ldl"]
+           "-fno-slp-vectorize", "-Wno-unused-value", *SOURCES, "-o", LIB + ".tmp", "-ldl"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)

@@ -50,16 +50,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   W1' : [8 T][4 s][2 hi/lo][64 lanes]      64 KB   (FFN 64->256, LN affine folded)
 //   W2  : [2 To][16 s][2][64]                64 KB   (FFN 256->64)
 //   Woc : [2 To][4 s][2][64]                 16 KB   (column out_proj)
+//   Wv' : [2 T][4 s][64] hi only              8 KB   (next block's row V projection; lo from L2)
+//   Wqk : [4 s][2][16]                         2 KB   (next block's row q/k rows, 8 of 32 rows)
 //   consts (floats): b1'[256] | b2[64] | bqk[8] | head_w[64] | head_b[1] | pad | bo_col[64]
-constexpr int FRAG_W1 = 0;
-constexpr int FRAG_W2 = FRAG_W1 + 8 * 4 * 2 * 64;
-constexpr int FRAG_WO = FRAG_W2 + 2 * 16 * 2 * 64;
-constexpr int FRAG_END = FRAG_WO + 2 * 4 * 2 * 64;          // in bf16x8 units
+constexpr int FRAG_W1 = 0;                                   // [8 T][4 s][2 hi/lo][64]
+constexpr int FRAG_W2 = FRAG_W1 + 8 * 4 * 2 * 64;            // [2 To][16 s][2][64]
+constexpr int FRAG_WO = FRAG_W2 + 2 * 16 * 2 * 64;           // [2 To][4 s][2][64]
+constexpr int FRAG_WV = FRAG_WO + 2 * 4 * 2 * 64;            // next row attn Wv' hi only: [2 T][4 s][64]
+constexpr int FRAG_QK = FRAG_WV + 2 * 4 * 64;                // next row attn [Wq';Wk'] rows 0..7 only:
+                                                             //   [4 s][2 hi/lo][2 kgrp][8 rows]
+constexpr int FRAG_END = FRAG_QK + 4 * 2 * 16;               // in bf16x8 (16-byte) units
+constexpr int WVLO_FRAGS = 2 * 4 * 64;                       // lo part of Wv', read from global
 constexpr int CONST_B1 = 0, CONST_B2 = 256, CONST_BQK = 320, CONST_HW = 328, CONST_HB = 392,
               CONST_BOC = 400;
 constexpr int CONST_LEN = 464;                                // floats
-constexpr int MAIN_LDS_BYTES = FRAG_END * 16 + CONST_LEN * 4; // 149,056 B
-constexpr int RVQK_FRAGS = 3 * 4 * 2 * 64;                    // next block's row [Wv';Wq';Wk'] frags
+constexpr int MAIN_LDS_BYTES = FRAG_END * 16 + CONST_LEN * 4; // 159,552 B of the 163,840 B LDS
+constexpr int MFRAG_PER_PAIR = 2 * 2 * 32;                    // row-mix fragments per pair (lanes h=0)
 
 constexpr int MAIN_THREADS = 512;  // 8 waves: two per SIMD so MFMA and VALU phases of different waves overlap
 constexpr int MAIN_WAVES = MAIN_THREADS / 64;
@@ -143,6 +149,60 @@ __device__ __forceinline__ float gelu_as(float x) {
 }
 __device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// FFN hidden activation for two accumulator values at once, fused with the bf16 hi/lo split.
+// The FFN weights are pre-scaled on the host so that the accumulator holds a*h with
+// a^2 = log2(e)/2 (then exp(-h^2/2) = exp2(-(a h)^2) needs no multiply) and W2 carries 1/a;
+// the function returns a*gelu(h) as packed bf16 pairs:  hi = bf16(g), lo = bf16(g - hi).
+//   gelu(h) = h/2 + |h| (1/2 - 1/2 poly(t) exp(-h^2/2)),  t = 1/(1 + p|h|/sqrt2)      (A&S 7.1.26)
+// Written so that hipcc (with -fno-slp-vectorize) emits packed v_pk_fma/mul for the polynomial
+// and scalar VOP3 forms with free |x| / -x modifiers elsewhere: ~52 VALU cycles per value.
+constexpr float GELU_ALPHA = 0.84932180028801904272f;   // sqrt(log2(e) / 2)
+__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {
+    const float C = 0.3275911f * 0.70710678118654752440f / GELU_ALPHA;
+    const float d0 = fmaf(fabsf(x0), C, 1.0f);
+    const float d1 = fmaf(fabsf(x1), C, 1.0f);
+    const f32x2 t = {__builtin_amdgcn_rcpf(d0), __builtin_amdgcn_rcpf(d1)};
+    const f32x2 x = {x0, x1};
+    const f32x2 s = x * x;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-s[0]), __builtin_amdgcn_exp2f(-s[1])};
+    // coefficients carry the factor 1/2
+    const f32x2 a5 = {0.5f * 1.061405429f, 0.5f * 1.061405429f}, a4 = {0.5f * -1.453152027f, 0.5f * -1.453152027f},
+                a3 = {0.5f * 1.421413741f, 0.5f * 1.421413741f}, a2 = {0.5f * -0.284496736f, 0.5f * -0.284496736f},
+                a1 = {0.5f * 0.254829592f, 0.5f * 0.254829592f}, half = {0.5f, 0.5f};
+    f32x2 p = __builtin_elementwise_fma(a5, t, a4);
+    p = __builtin_elementwise_fma(p, t, a3);
+    p = __builtin_elementwise_fma(p, t, a2);
+    p = __builtin_elementwise_fma(p, t, a1);
+    const f32x2 pt = p * t;
+    const f32x2 w = __builtin_elementwise_fma(-pt, e, half);          // Phi(|h|) - 1/2
+    const f32x2 u = {fabsf(x0) * w[0], fabsf(x1) * w[1]};
+    const f32x2 g = __builtin_elementwise_fma(x, half, u);
+    const bf16x2 h2 = {(__bf16)g[0], (__bf16)g[1]};
+    const unsigned hb = __builtin_bit_cast(unsigned, h2);
+    const f32x2 f = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+    const f32x2 r = g - f;
+    const bf16x2 l2 = {(__bf16)r[0], (__bf16)r[1]};
+    hi_out = hb;
+    lo_out = __builtin_bit_cast(unsigned, l2);
+}
+// eight accumulator values acc[base .. base+7] -> one B-operand fragment pair
+__device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned a, b;
+        gelu_split_pair(acc[base + 2 * k], acc[base + 2 * k + 1], a, b);
+        h[k] = a;
+        l[k] = b;
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
 // split 8 floats into bf16 hi + bf16 lo (x ~= hi + lo to 2^-17 relative)
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -184,13 +244,13 @@ struct MainArgs {
     float* x;               // [B][P][Lloc][64] in/out
     float* qrow;            // [B][P][Lloc][4]  in: q' of this block's row attn; out: next block's
     const float* qcol;      // [B][P][Lloc][4]
-    const float* mrow;      // [B][P][5][64]
+    const bf16x8* mfrag;    // [B][P][2 To][2 hi/lo][32] row mix M^T (+bias row) as MFMA A fragments
     const float* ctx;       // [B][Lloc][64]
     float* srow;            // [B][P][72]  out: statistics for the next block's row attn
     float* out;             // [B][P]      out (last block): sum_l softplus / L_total
-    const bf16x8* wimg;     // this block's LDS image (FRAG_END fragments) in global memory
-    const float* consts;    // this block's CONST_LEN floats
-    const bf16x8* rvqk;     // RVQK_FRAGS fragments for the next row attn (global, L2-resident)
+    const bf16x8* wimg;     // LDS image (FRAG_END fragments) in global memory
+    const float* consts;    // CONST_LEN floats
+    const bf16x8* wv_lo;    // [2 T][4 s][64] lo fragments of the next row attn's Wv' (global, L1/L2)
     const float* table;     // [22][64] relu(W_emb + b_emb)          (MODE_FIRST)
     const uint8_t* idx;     // [B][N][Lloc]                           (MODE_FIRST)
     const int16_t* pair_i;  // [P]                                    (MODE_FIRST)
@@ -204,6 +264,23 @@ struct MainArgs {
 
 enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
 
+__device__ __forceinline__ void load_acc_bias(f32x16& acc, const float* lds_bias, int h) {
+    // acc[r] = bias[row(r, h)], row = 8*(r>>2) + 4*h + (r&3): four 16-byte LDS reads
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(lds_bias + 8 * q4 + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q4 + i] = bb[i];
+    }
+}
+
+__device__ __forceinline__ bf16x8 zero_frag() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+    return z;
+}
+
 // One wave owns one (alignment, pair) row at a time and walks its sites in
 // tiles of 32 tokens; waves never synchronise with each other after the LDS
 // image is loaded.
@@ -211,17 +288,18 @@ enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
 //   MODE_MID  : row-apply + col-apply + FFN of block k;      -> row stats of block k+1
 //   MODE_LAST : row-apply + col-apply + FFN of the last block -> softplus head, site mean
 template <int MODE>
-__global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
+__global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bf16x8* lw = reinterpret_cast<const bf16x8*>(smem);
     const float* lc = reinterpret_cast<const float*>(smem + FRAG_END * 16);
 
-    if (MODE != MODE_FIRST) {
+    {
         uint4* dst = reinterpret_cast<uint4*>(smem);
         const uint4* src = reinterpret_cast<const uint4*>(a.wimg);
-        for (int i = threadIdx.x; i < FRAG_END; i += MAIN_THREADS) dst[i] = src[i];
-    }
-    {
+        // MODE_FIRST only needs the row-statistics operands; the last block only the FFN/out_proj
+        const int lo = (MODE == MODE_FIRST) ? FRAG_WV : 0;
+        const int hi = (MODE == MODE_LAST) ? FRAG_WV : FRAG_END;
+        for (int i = lo + threadIdx.x; i < hi; i += MAIN_THREADS) dst[i] = src[i];
         float* dc = reinterpret_cast<float*>(smem + FRAG_END * 16);
         for (int i = threadIdx.x; i < CONST_LEN; i += MAIN_THREADS) dc[i] = a.consts[i];
     }
@@ -233,25 +311,13 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
     const int h = lane >> 5;
     const int ntiles = (a.Lloc + 31) >> 5;
     const int ntasks = a.B * a.P;
+    const bf16x8* w1p = lw + FRAG_W1 + lane;   // per-lane fragment bases: all later offsets are immediates
+    const bf16x8* w2p = lw + FRAG_W2 + lane;
 
     for (int task = blockIdx.x * MAIN_WAVES + wave; task < ntasks; task += gridDim.x * MAIN_WAVES) {
         const int b = task / a.P;
         const int p = task - b * a.P;
         const size_t row0 = (size_t)task * a.Lloc;  // first token of this pair row
-
-        // ---- per-pair operands ------------------------------------------------------------
-        bf16x8 ma_hi[2], ma_lo[2];  // row mix M^T (+ bias row) as A fragments, K padded 5 -> 16
-        if (MODE != MODE_FIRST) {
-            const float* mr = a.mrow + (size_t)task * MROW;
-#pragma unroll
-            for (int To = 0; To < 2; ++To) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    v[i] = (h == 0 && i < 5) ? mr[i * 64 + 32 * To + t] : 0.f;
-                split8(v, ma_hi[To], ma_lo[To]);
-            }
-        }
         int ai = 0, aj = 0;
         if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
 
@@ -292,104 +358,99 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
                         for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] : 0.f;
                     }
                 }
-                // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
                 if (!(a.ablate & 8)) {
-                f32x16 ya[2];  // starts from the column out_proj bias
+                    f32x16 ya[2];  // starts from the column out_proj bias
+                    load_acc_bias(ya[0], lc + CONST_BOC, h);
+                    load_acc_bias(ya[1], lc + CONST_BOC + 32, h);
+                    // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
+                    {
+                        const f32x4 qr = *reinterpret_cast<const f32x4*>(a.qrow + tok * 4);
+                        float v[8];
 #pragma unroll
-                for (int To = 0; To < 2; ++To) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 bb = *reinterpret_cast<const f32x4*>(
-                            lc + CONST_BOC + 32 * To + 8 * q4 + 4 * h);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ya[To][4 * q4 + i] = bb[i];
-                    }
-                }
-                {
-                    const f32x4 qr = *reinterpret_cast<const f32x4*>(a.qrow + tok * 4);
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
-                    v[4] = (h == 0) ? 1.f : 0.f;
-                    v[5] = v[6] = v[7] = 0.f;
-                    bf16x8 qb_hi, qb_lo;
-                    split8(v, qb_hi, qb_lo);
-#pragma unroll
-                    for (int To = 0; To < 2; ++To) mfma3(ya[To], ma_hi[To], ma_lo[To], qb_hi, qb_lo);
-                }
-                // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
-                {
-                    const f32x4 qc = *reinterpret_cast<const f32x4*>(a.qcol + tok * 4);
-                    const f32x4* cp = reinterpret_cast<const f32x4*>(
-                        a.ctx + ((size_t)b * a.Lloc + lc_) * 64 + 4 * h);
-                    float o[32];
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        f32x4 u = cp[2 * g];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[4 * g + i] = u[i] * qc[g >> 1];
-                    }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        bf16x8 ob_hi, ob_lo;
-                        split8(&o[8 * s], ob_hi, ob_lo);
+                        for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
+                        v[4] = (h == 0) ? 1.f : 0.f;
+                        v[5] = v[6] = v[7] = 0.f;
+                        bf16x8 qb_hi, qb_lo;
+                        split8(v, qb_hi, qb_lo);
+                        const bf16x8* mf = a.mfrag + (size_t)task * 128 + t;
 #pragma unroll
                         for (int To = 0; To < 2; ++To) {
-                            const bf16x8* f = lw + FRAG_WO + ((To * 4 + s) * 2) * 64 + lane;
-                            mfma3(ya[To], f[0], f[64], ob_hi, ob_lo);
+                            bf16x8 m_hi = zero_frag(), m_lo = zero_frag();
+                            if (h == 0) { m_hi = mf[To * 64]; m_lo = mf[To * 64 + 32]; }
+                            mfma3(ya[To], m_hi, m_lo, qb_hi, qb_lo);
                         }
                     }
-                }
+                    // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
+                    {
+                        const f32x4 qc = *reinterpret_cast<const f32x4*>(a.qcol + tok * 4);
+                        const f32x4* cp = reinterpret_cast<const f32x4*>(
+                            a.ctx + ((size_t)b * a.Lloc + lc_) * 64 + 4 * h);
+                        float o[32];
 #pragma unroll
-                for (int j = 0; j < 32; ++j) x[j] += ya[j >> 4][j & 15];
+                        for (int g = 0; g < 8; ++g) {
+                            f32x4 u = cp[2 * g];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[4 * g + i] = u[i] * qc[g >> 1];
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            bf16x8 ob_hi, ob_lo;
+                            split8(&o[8 * s], ob_hi, ob_lo);
+#pragma unroll
+                            for (int To = 0; To < 2; ++To) {
+                                const bf16x8* f = lw + FRAG_WO + ((To * 4 + s) * 2) * 64 + lane;
+                                mfma3(ya[To], f[0], f[64], ob_hi, ob_lo);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) x[j] += ya[j >> 4][j & 15];
                 }
 
                 // ---- feed-forward (model.py:101-104): x += W2 gelu(W1' x~ + b1') + b2
                 if (!(a.ablate & 16)) {
-                    float xn[32];
-                    ln_pair(x, xn);
                     bf16x8 xb_hi[4], xb_lo[4];
+                    {
+                        float xn[32];
+                        ln_pair(x, xn);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) split8(&xn[8 * s], xb_hi[s], xb_lo[s]);
-                    f32x16 oa[2];
-#pragma unroll
-                    for (int To = 0; To < 2; ++To) {
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const f32x4 bb = *reinterpret_cast<const f32x4*>(
-                                lc + CONST_B2 + 32 * To + 8 * q4 + 4 * h);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) oa[To][4 * q4 + i] = bb[i];
-                        }
+                        for (int s = 0; s < 4; ++s) split8(&xn[8 * s], xb_hi[s], xb_lo[s]);
                     }
+                    f32x16 oa[2];
+                    load_acc_bias(oa[0], lc + CONST_B2, h);
+                    load_acc_bias(oa[1], lc + CONST_B2 + 32, h);
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
                         f32x16 ha;
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const f32x4 bb = *reinterpret_cast<const f32x4*>(
-                                lc + CONST_B1 + 32 * T + 8 * q4 + 4 * h);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) ha[4 * q4 + i] = bb[i];
-                        }
+                        load_acc_bias(ha, lc + CONST_B1 + 32 * T, h);
+                        const bf16x8* f1 = w1p + T * 512;
+                        const bf16x8* f2 = w2p + T * 256;
+                        // software-pipelined fragment reads: the next step's A operands are in
+                        // flight while the current step's three MFMAs issue
+                        bf16x8 fh = f1[0], fl = f1[64];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            const bf16x8* f = lw + FRAG_W1 + ((T * 4 + s) * 2) * 64 + lane;
-                            mfma3(ha, f[0], f[64], xb_hi[s], xb_lo[s]);
+                            bf16x8 nh, nl;
+                            if (s < 3) { nh = f1[(s + 1) * 128]; nl = f1[(s + 1) * 128 + 64]; }
+                            else { nh = f2[0]; nl = f2[64]; }
+                            mfma3(ha, fh, fl, xb_hi[s], xb_lo[s]);
+                            fh = nh; fl = nl;
                         }
-                        float gv[16];
+                        bf16x8 g_hi[2], g_lo[2];
+                        gelu_split8(ha, 0, g_hi[0], g_lo[0]);
+                        gelu_split8(ha, 8, g_hi[1], g_lo[1]);
+                        // GEMM2 steps in (u, To) order; fragment (To, 2T+u) lives at f2[(To*32 + u*2)*64]
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) gv[r] = gelu_as(ha[r]);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            bf16x8 g_hi, g_lo;
-                            split8(&gv[8 * u], g_hi, g_lo);
-#pragma unroll
-                            for (int To = 0; To < 2; ++To) {
-                                const bf16x8* f =
-                                    lw + FRAG_W2 + ((To * 16 + 2 * T + u) * 2) * 64 + lane;
-                                mfma3(oa[To], f[0], f[64], g_hi, g_lo);
+                        for (int st = 0; st < 4; ++st) {
+                            const int u = st >> 1, To = st & 1;
+                            bf16x8 nh = fh, nl = fl;
+                            if (st < 3) {
+                                const int nu = (st + 1) >> 1, nTo = (st + 1) & 1;
+                                nh = f2[(nTo * 32 + nu * 2) * 64];
+                                nl = f2[(nTo * 32 + nu * 2) * 64 + 64];
                             }
+                            mfma3(oa[To], fh, fl, g_hi[u], g_lo[u]);
+                            fh = nh; fl = nl;
                         }
                     }
 #pragma unroll
@@ -399,8 +460,14 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
 
             if (MODE != MODE_LAST && !(a.ablate & 4)) {
                 // ---- statistics of the next block's row attention (attention.py:163-190)
-                float xn[32];
-                ln_pair(x, xn);
+                if (valid && !(a.ablate & 2)) {
+                    f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        f32x4 u = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                        xo[2 * g] = u;
+                    }
+                }
                 f32x16 va[3];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -408,14 +475,25 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
                     va[1][r] = 0.f;
                     va[2][r] = (r < 4) ? lc[CONST_BQK + 4 * h + r] : 0.f;  // rows 0-3 q, 4-7 k
                 }
+                {
+                    float xn[32];
+                    ln_pair(x, xn);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    bf16x8 xb_hi, xb_lo;
-                    split8(&xn[8 * s], xb_hi, xb_lo);
+                    for (int s = 0; s < 4; ++s) {
+                        bf16x8 xb_hi, xb_lo;
+                        split8(&xn[8 * s], xb_hi, xb_lo);
 #pragma unroll
-                    for (int T = 0; T < 3; ++T) {
-                        const bf16x8* f = a.rvqk + ((T * 4 + s) * 2) * 64 + lane;
-                        mfma3(va[T], f[0], f[64], xb_hi, xb_lo);
+                        for (int T = 0; T < 2; ++T) {
+                            const bf16x8 f_hi = lw[FRAG_WV + (T * 4 + s) * 64 + lane];
+                            const bf16x8 f_lo = a.wv_lo[(T * 4 + s) * 64 + lane];
+                            mfma3(va[T], f_hi, f_lo, xb_hi, xb_lo);
+                        }
+                        bf16x8 q_hi = zero_frag(), q_lo = zero_frag();
+                        if (t < 8) {
+                            q_hi = lw[FRAG_QK + (s * 2) * 16 + h * 8 + t];
+                            q_lo = lw[FRAG_QK + (s * 2 + 1) * 16 + h * 8 + t];
+                        }
+                        mfma3(va[2], q_hi, q_lo, xb_hi, xb_lo);
                     }
                 }
                 float qk[4], ot[4];
@@ -441,12 +519,6 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
                     if (h == 0) {
                         f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
                         *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = qs;
-                    }
-                    f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        f32x4 u = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
-                        xo[2 * g] = u;
                     }
                 }
             } else if (MODE == MODE_LAST) {
@@ -477,13 +549,11 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s_q[i] = half32_sum(s_q[i]); s_k[i] = half32_sum(s_k[i]); }
             sr[kmap(t, h)] = s_kv;
-            if (t == 0) {
-                if (h == 0) {
-                    f32x4 u = {s_q[0], s_q[1], s_q[2], s_q[3]};
-                    f32x4 w = {s_k[0], s_k[1], s_k[2], s_k[3]};
-                    *reinterpret_cast<f32x4*>(sr + 64) = u;
-                    *reinterpret_cast<f32x4*>(sr + 68) = w;
-                }
+            if (lane == 0) {
+                f32x4 u = {s_q[0], s_q[1], s_q[2], s_q[3]};
+                f32x4 w = {s_k[0], s_k[1], s_k[2], s_k[3]};
+                *reinterpret_cast<f32x4*>(sr + 64) = u;
+                *reinterpret_cast<f32x4*>(sr + 68) = w;
             }
         } else {
             s_out = half32_sum(s_out);
@@ -495,7 +565,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, 2) k_main(MainArgs a) {
 // ---- row finalisation: srow -> mrow ------------------------------------------------------
 struct RowFinArgs {
     const float* srow;   // [B*P][72]
-    float* mrow;         // [B*P][5][64]
+    float* mrow;         // [B*P][5][64]   fp32 (k_colstats)
+    bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments (k_main)
     const float* woT;    // [64 hd][64 c]  row out_proj, transposed
     const float* bv;     // [64] folded row v bias
     const float* bias;   // [64] row out_proj bias
@@ -504,7 +575,8 @@ struct RowFinArgs {
 };
 
 __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
-    __shared__ float ctx[4][64];  // 4 pairs per block
+    __shared__ float ctx[4][64];      // 4 pairs per block
+    __shared__ float mm[4][5][64];
     const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
     const int pr = blockIdx.x * 4 + sub;
     const bool ok = pr < a.npairs;
@@ -524,8 +596,23 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
 #pragma unroll
             for (int d = 0; d < 16; ++d) acc = fmaf(a.woT[(16 * hh + d) * 64 + c], ctx[sub][16 * hh + d], acc);
             m[hh * 64 + c] = acc;
+            mm[sub][hh][c] = acc;
         }
         m[4 * 64 + c] = a.bias[c];
+        mm[sub][4][c] = a.bias[c];
+    }
+    __syncthreads();
+    if (ok) {
+        // A fragments of M^T for k_main's row-apply MFMA: lane t of half 0 holds K slots 0..4
+        const int To = c >> 5, t = c & 31;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (i < 5) ? mm[sub][i][32 * To + t] : 0.f;
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        bf16x8* mf = a.mfrag + (size_t)pr * MFRAG_PER_PAIR + To * 64 + t;
+        mf[0] = hi;
+        mf[32] = lo;
     }
 }
 

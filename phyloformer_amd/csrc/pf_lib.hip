@@ -107,10 +107,39 @@ void pack_frags(const float* W, int M, int K, int Mpad, uint16_t* out) {
                 }
 }
 
+// Row-statistics operands of one block's row attention, in the layout of the LDS image tail:
+//   [FRAG_WV ..): Wv' hi fragments [2 T][4 s][64];  [FRAG_QK ..): rows 0..7 of [Wq';Wk'] as
+//   [4 s][2 hi/lo][2 kgrp][8 rows];  wv_lo: Wv' lo fragments [2 T][4 s][64] (stays in global).
+void pack_row_stats(const float* wv, const float* wq, const float* wk, uint16_t* img_tail /* from FRAG_WV */,
+                    uint16_t* wv_lo) {
+    std::vector<uint16_t> full((size_t)2 * 4 * 2 * 64 * 8);
+    pack_frags(wv, E, E, E, full.data());
+    for (int T = 0; T < 2; ++T)
+        for (int s = 0; s < 4; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const size_t src = (((size_t)(T * 4 + s) * 2) * 64 + lane) * 8 + i;
+                    const size_t dst = ((size_t)(T * 4 + s) * 64 + lane) * 8 + i;
+                    img_tail[dst] = full[src];
+                    wv_lo[dst] = full[src + 64 * 8];
+                }
+    uint16_t* qk = img_tail + (size_t)(FRAG_QK - FRAG_WV) * 8;
+    for (int s = 0; s < 4; ++s)
+        for (int kg = 0; kg < 2; ++kg)
+            for (int m = 0; m < 8; ++m)
+                for (int i = 0; i < 8; ++i) {
+                    const int k = kmap_h(8 * s + i, kg);
+                    const float w = (m < 4) ? wq[(size_t)m * E + k] : wk[(size_t)(m - 4) * E + k];
+                    const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+                    qk[(((size_t)s * 2 + 0) * 16 + kg * 8 + m) * 8 + i] = hi;
+                    qk[(((size_t)s * 2 + 1) * 16 + kg * 8 + m) * 8 + i] = lo;
+                }
+}
+
 struct BlockDev {
     float* wimg = nullptr;     // LDS image: FRAG_END frags (as bytes) ; stored as raw
     float* consts = nullptr;   // CONST_LEN
-    float* rvqk = nullptr;     // RVQK_FRAGS frags for THIS block's row attention
+    float* wv_lo = nullptr;    // lo fragments of THIS block's row Wv' (WVLO_FRAGS)
     float* bqk_row = nullptr;  // (host copy lives in consts of the previous stage)
     float* row_woT = nullptr;  // [64][64]
     float* row_bv = nullptr;   // [64]
@@ -142,6 +171,7 @@ struct pf_handle {
     // weights
     float* table = nullptr;       // [22][64]
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
+    float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
     std::vector<BlockDev> blk;
     std::vector<void*> owned;     // every device allocation made at create
     // pair index tables
@@ -262,6 +292,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
                     (unsigned long long)w->blob_len, (unsigned long long)(bl.p - w->blob));
 
     std::vector<std::vector<float>> row_bqk(nb);
+    std::vector<std::vector<uint16_t>> row_tail(nb);
     for (int k = 0; k < nb; ++k) {
         BlockDev& d = h->blk[k];
         const AttnHost& r = rows[k];
@@ -271,13 +302,10 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         fold(r.wq, r.bq, r.g, r.b, NH, E, wq, bq);
         fold(r.wk, r.bk, r.g, r.b, NH, E, wk, bk);
         fold(r.wv, r.bv, r.g, r.b, E, E, wv, bv);
-        std::vector<float> vqk((size_t)72 * E);
-        std::copy(wv.begin(), wv.end(), vqk.begin());
-        std::copy(wq.begin(), wq.end(), vqk.begin() + 64 * E);
-        std::copy(wk.begin(), wk.end(), vqk.begin() + 68 * E);
-        std::vector<uint16_t> rv((size_t)RVQK_FRAGS * 8);
-        pack_frags(vqk.data(), 72, E, 96, rv.data());
-        if ((rc = upload(h, rv, &d.rvqk))) return rc;
+        row_tail[k].assign((size_t)(FRAG_END - FRAG_WV) * 8, 0);
+        std::vector<uint16_t> wvlo((size_t)WVLO_FRAGS * 8);
+        pack_row_stats(wv.data(), wq.data(), wk.data(), row_tail[k].data(), wvlo.data());
+        if ((rc = upload(h, wvlo, &d.wv_lo))) return rc;
         row_bqk[k].assign(8, 0.f);
         for (int i = 0; i < 4; ++i) { row_bqk[k][i] = bq[i]; row_bqk[k][4 + i] = bk[i]; }
         std::vector<float> woT((size_t)E * E);
@@ -308,10 +336,18 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         // ---- LDS image of k_main(k): FFN + column out_proj
         std::vector<float> w1f, b1f;
         fold(ffn[k].w1, ffn[k].b1, ffn[k].g, ffn[k].b, FF, E, w1f, b1f);
+        // hidden pre-activations are carried as a*h, a = sqrt(log2(e)/2) (see gelu_split_pair);
+        // W2 absorbs 1/a
+        const double alpha = std::sqrt(0.5 * 1.4426950408889634074);
+        for (auto& v : w1f) v = (float)((double)v * alpha);
+        for (auto& v : b1f) v = (float)((double)v * alpha);
+        std::vector<float> w2s((size_t)E * FF);
+        for (size_t i = 0; i < w2s.size(); ++i) w2s[i] = (float)((double)ffn[k].w2[i] / alpha);
         std::vector<uint16_t> img((size_t)FRAG_END * 8);
         pack_frags(w1f.data(), FF, E, FF, img.data() + (size_t)FRAG_W1 * 8);
-        pack_frags(ffn[k].w2, E, FF, E, img.data() + (size_t)FRAG_W2 * 8);
+        pack_frags(w2s.data(), E, FF, E, img.data() + (size_t)FRAG_W2 * 8);
         pack_frags(cols[k].wo, E, E, E, img.data() + (size_t)FRAG_WO * 8);
+        if (k + 1 < nb) std::copy(row_tail[k + 1].begin(), row_tail[k + 1].end(), img.begin() + (size_t)FRAG_WV * 8);
         if ((rc = upload(h, img, &d.wimg))) return rc;
         std::vector<float> cst(CONST_LEN, 0.f);
         std::copy(b1f.begin(), b1f.end(), cst.begin() + CONST_B1);
@@ -324,6 +360,9 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
     }
     std::vector<float> cst0(CONST_LEN, 0.f);
     std::copy(row_bqk[0].begin(), row_bqk[0].end(), cst0.begin() + CONST_BQK);
+    std::vector<uint16_t> img0((size_t)FRAG_END * 8, 0);
+    std::copy(row_tail[0].begin(), row_tail[0].end(), img0.begin() + (size_t)FRAG_WV * 8);
+    if ((rc = upload(h, img0, &h->first_img))) return rc;
     return upload(h, cst0, &h->first_consts);
 }
 
@@ -347,7 +386,7 @@ int ensure_pairs(pf_handle* h, int N) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx;
+    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag;
     int G;
 };
 
@@ -368,6 +407,7 @@ size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[8]) {
     off[4] = o; o = align_up(o + (size_t)B * P * MROW * 4, 256);         // mrow
     off[5] = o; o = align_up(o + (size_t)B * G * Lloc * CPART * 4, 256); // part
     off[6] = o; o = align_up(o + (size_t)B * Lloc * 64 * 4, 256);        // ctx
+    off[7] = o; o = align_up(o + (size_t)B * P * MFRAG_PER_PAIR * 16, 256); // mfrag
     return o;
 }
 
@@ -384,6 +424,7 @@ int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w) {
     w->qcol = (float*)(h->ws + off[2]); w->srow = (float*)(h->ws + off[3]);
     w->mrow = (float*)(h->ws + off[4]); w->part = (float*)(h->ws + off[5]);
     w->ctx = (float*)(h->ws + off[6]);
+    w->mfrag = (float*)(h->ws + off[7]);
     return PF_OK;
 }
 
@@ -459,14 +500,14 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
     const int nb = h->n_blocks;
 
     MainArgs m{};
-    m.x = w.x; m.qrow = w.qrow; m.qcol = w.qcol; m.mrow = w.mrow; m.ctx = w.ctx; m.srow = w.srow;
+    m.x = w.x; m.qrow = w.qrow; m.qcol = w.qcol; m.mfrag = reinterpret_cast<const bf16x8*>(w.mfrag); m.ctx = w.ctx; m.srow = w.srow;
     m.out = d_out; m.table = h->table; m.idx = d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
     m.B = B; m.N = N; m.P = P; m.Lloc = Lloc; m.inv_L_total = 1.0f / (float)L_total;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.ablate = h->ablate;
 
-    m.wimg = nullptr; m.consts = h->first_consts;
-    m.rvqk = reinterpret_cast<const bf16x8*>(h->blk[0].rvqk);
+    m.wimg = reinterpret_cast<const bf16x8*>(h->first_img); m.consts = h->first_consts;
+    m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[0].wv_lo);
     if ((rc = launch_main<MODE_FIRST>(h, m, K_EMBED))) return rc;
     const size_t ntok = (size_t)B * P * Lloc;
     if (h->debug_keep && (rc = save_tap(h, "x0", w.x, ntok * 64))) return rc;
@@ -476,7 +517,7 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
         if ((rc = allreduce(h, w.srow, (size_t)B * P * SROW))) return rc;
         if (h->debug_keep && (rc = save_tap(h, "srow" + std::to_string(k), w.srow, (size_t)B * P * SROW))) return rc;
         {
-            RowFinArgs a{w.srow, w.mrow, d.row_woT, d.row_bv, d.row_bo, B * P, (float)L_total};
+            RowFinArgs a{w.srow, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag), d.row_woT, d.row_bv, d.row_bo, B * P, (float)L_total};
             ProfScope ps(h, K_ROWFIN);
             hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
             HIPCHK(h, hipGetLastError());
@@ -500,10 +541,10 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
         m.wimg = reinterpret_cast<const bf16x8*>(d.wimg);
         m.consts = d.consts;
         if (k + 1 < nb) {
-            m.rvqk = reinterpret_cast<const bf16x8*>(h->blk[k + 1].rvqk);
+            m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[k + 1].wv_lo);
             if ((rc = launch_main<MODE_MID>(h, m, K_MAIN))) return rc;
         } else {
-            m.rvqk = nullptr;
+            m.wv_lo = nullptr;
             if ((rc = launch_main<MODE_LAST>(h, m, K_MAIN))) return rc;
         }
         if (h->debug_keep && (rc = save_tap(h, "x" + std::to_string(k + 1), w.x, ntok * 64))) return rc;
