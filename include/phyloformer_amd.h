@@ -153,6 +153,12 @@ int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap)
 int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_count,
                    uint64_t* hbm_bytes);
 
+/* Single-GPU emulation of pf_forward_sharded over `nshards` ranks (test backend): same kernels
+ * and per-shard workspaces as real ranks, the RCCL all-reduces replaced by device-side sums.
+ * idx: host uint8 [B][N][L]; out: host float [B][P]. */
+int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t L,
+                               int32_t nshards, float* out);
+
 /* Hardware-layout self test: one wave exercises the cross-lane primitives and one
  * MFMA with known operands; `out` receives 2304 floats (layout in
  * phyloformer_amd/csrc/pf_device.hip.h::k_selftest).  tests/test_gpu_selftest.py

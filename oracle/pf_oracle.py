@@ -101,7 +101,7 @@ def attention_apply(q, s_q, s_k, s_kv, w, pre, count):
     qn = q / (s_q / dt.type(count))                          # q / q.mean(dim=-2)
     ctx = s_kv / s_k[..., None]                              # (k / k.sum)ᵀ @ v
     o = qn[..., None] * ctx                                  # [..., H, D]
-    o = o.reshape(o.shape[:-2] + (-1,))
+    o = o.reshape(o.shape[:-2] + (o.shape[-2] * o.shape[-1],))
     return _mm(o, w[pre + "out_proj.weight"].astype(dt)) + w[pre + "out_proj.bias"].astype(dt)
 
 
@@ -187,6 +187,48 @@ def forward(weights: Dict[str, np.ndarray], idx: np.ndarray, *, n_blocks: int = 
     if tap:
         tap("dist", d)
     return d.astype(dt)
+
+
+def forward_rank(weights: Dict[str, np.ndarray], idx_local: np.ndarray, L_total: int,
+                 allreduce: Callable[[np.ndarray], np.ndarray], *, n_blocks: int = 6,
+                 n_heads: int = 4, dtype=np.float32) -> np.ndarray:
+    """One rank of the site-sharded forward: ``idx_local`` is ``uint8[N, Lloc]`` (Lloc may be 0).
+
+    ``allreduce(a)`` must return the element-wise sum of ``a`` over all ranks.  It is called
+    ``n_blocks + 1`` times with arrays of identical shape on every rank: the fused row
+    statistics ``[P, 72]`` (S_kv | S_q | S_k) once per block and the site sums ``[P]`` at the
+    end — the collective schedule of the device path.
+    """
+    idx_local = np.asarray(idx_local)
+    N, Lloc = idx_local.shape
+    dt = np.dtype(dtype)
+    w = weights
+    pi, pj = pair_index(N)
+    P = len(pi)
+    e = embedding_table(w, dt)[idx_local]
+    x = e[pi] + e[pj]                                        # [P, Lloc, E]
+    for b in range(n_blocks):
+        p = f"attention_blocks.{b}."
+        g, bb = w[p + "row_norm.weight"].astype(dt), w[p + "row_norm.bias"].astype(dt)
+        q, s_q, s_k, s_kv = attention_stats(layer_norm(x, g, bb), w, p + "row_attention.", 1, n_heads)
+        fused = np.concatenate([s_kv.reshape(P, -1), s_q.reshape(P, -1), s_k.reshape(P, -1)], axis=1)
+        fused = allreduce(np.ascontiguousarray(fused, dtype=dt))
+        s_kv = fused[:, :-2 * n_heads].reshape(P, 1, n_heads, -1)
+        s_q = fused[:, -2 * n_heads:-n_heads].reshape(P, 1, n_heads)
+        s_k = fused[:, -n_heads:].reshape(P, 1, n_heads)
+        if Lloc:
+            x = x + attention_apply(q, s_q, s_k, s_kv, w, p + "row_attention.", L_total)
+        g, bb = w[p + "col_norm.weight"].astype(dt), w[p + "col_norm.bias"].astype(dt)
+        if Lloc:
+            q, a, k_, kv = attention_stats(layer_norm(x, g, bb), w, p + "col_attention.", 0, n_heads)
+            x = x + attention_apply(q, a, k_, kv, w, p + "col_attention.", P)
+        g, bb = w[p + "ffn_norm.weight"].astype(dt), w[p + "ffn_norm.bias"].astype(dt)
+        W1, b1 = w[p + "ffn.0.weight"].astype(dt), w[p + "ffn.0.bias"].astype(dt)
+        W2, b2 = w[p + "ffn.3.weight"].astype(dt), w[p + "ffn.3.bias"].astype(dt)
+        x = x + (_mm(gelu(_mm(layer_norm(x, g, bb), W1) + b1), W2) + b2)
+    hw, hb = w["pwFNN.0.weight"].astype(dt).reshape(-1), w["pwFNN.0.bias"].astype(dt)
+    part = softplus(_mm(x, hw[None, :])[..., 0] + hb).sum(axis=1).astype(dt)
+    return (allreduce(np.ascontiguousarray(part)) / dt.type(L_total)).astype(dt)
 
 
 def forward_batch(weights, idx: np.ndarray, **kw) -> np.ndarray:

@@ -770,6 +770,12 @@ __global__ void __launch_bounds__(256) k_colfin(ColFinArgs a) {
     }
 }
 
+// dst += src (stands in for the all-reduce in the single-GPU shard emulation)
+__global__ void k_accumulate(float* dst, const float* src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // ---- self test of the hardware-layout assumptions ------------------------------------------
 // out[0..63]: pair_sum(lane)        expected lane%32 + lane%32+32
 // out[64..127]: pair_other(lane)    expected lane ^ 32

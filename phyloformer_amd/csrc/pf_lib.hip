@@ -490,66 +490,92 @@ int launch_main(pf_handle* h, const MainArgs& a, int kid) {
     return PF_OK;
 }
 
-// one batch chunk, everything resident on the device
-int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, int L_total, float* d_out) {
-    const int P = N * (N - 1) / 2;
+// ---- the forward pass as phases over one shard's workspace -------------------------------------
+struct ShardRun {
     Workspace w;
-    int rc = ensure_workspace(h, B, P, Lloc, &w);
-    if (rc) return rc;
-    if ((rc = ensure_pairs(h, N))) return rc;
-    const int nb = h->n_blocks;
+    const uint8_t* d_idx;
+    float* d_out;
+    int B, N, P, Lloc, L_total;
+};
 
+MainArgs main_args(pf_handle* h, const ShardRun& r) {
     MainArgs m{};
-    m.x = w.x; m.qrow = w.qrow; m.qcol = w.qcol; m.mfrag = reinterpret_cast<const bf16x8*>(w.mfrag); m.ctx = w.ctx; m.srow = w.srow;
-    m.out = d_out; m.table = h->table; m.idx = d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
-    m.B = B; m.N = N; m.P = P; m.Lloc = Lloc; m.inv_L_total = 1.0f / (float)L_total;
+    m.x = r.w.x; m.qrow = r.w.qrow; m.qcol = r.w.qcol;
+    m.mfrag = reinterpret_cast<const bf16x8*>(r.w.mfrag); m.ctx = r.w.ctx; m.srow = r.w.srow;
+    m.out = r.d_out; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
+    m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc; m.inv_L_total = 1.0f / (float)r.L_total;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.ablate = h->ablate;
+    return m;
+}
 
+// embedding + pair expansion + row statistics of block 0
+int phase_first(pf_handle* h, const ShardRun& r) {
+    MainArgs m = main_args(h, r);
     m.wimg = reinterpret_cast<const bf16x8*>(h->first_img); m.consts = h->first_consts;
     m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[0].wv_lo);
-    if ((rc = launch_main<MODE_FIRST>(h, m, K_EMBED))) return rc;
-    const size_t ntok = (size_t)B * P * Lloc;
-    if (h->debug_keep && (rc = save_tap(h, "x0", w.x, ntok * 64))) return rc;
+    int rc = launch_main<MODE_FIRST>(h, m, K_EMBED);
+    if (rc) return rc;
+    if (h->debug_keep) return save_tap(h, "x0", r.w.x, (size_t)r.B * r.P * r.Lloc * 64);
+    return PF_OK;
+}
 
-    for (int k = 0; k < nb; ++k) {
-        const BlockDev& d = h->blk[k];
-        if ((rc = allreduce(h, w.srow, (size_t)B * P * SROW))) return rc;
-        if (h->debug_keep && (rc = save_tap(h, "srow" + std::to_string(k), w.srow, (size_t)B * P * SROW))) return rc;
-        {
-            RowFinArgs a{w.srow, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag), d.row_woT, d.row_bv, d.row_bo, B * P, (float)L_total};
-            ProfScope ps(h, K_ROWFIN);
-            hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
-            HIPCHK(h, hipGetLastError());
-        }
-        {
-            ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 3) / 4};
-            ProfScope ps(h, K_COLSTATS);
-            hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
-            HIPCHK(h, hipGetLastError());
-        }
-        {
-            ColFinArgs a{w.part, w.ctx, d.col_wvT, d.col_bv, B, Lloc, w.G, (float)P};
-            ProfScope ps(h, K_COLFIN);
-            hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(256), 0, h->stream, a);
-            HIPCHK(h, hipGetLastError());
-        }
-        if (h->debug_keep) {
-            if ((rc = save_tap(h, "ctx" + std::to_string(k), w.ctx, (size_t)B * Lloc * 64))) return rc;
-            if ((rc = save_tap(h, "mrow" + std::to_string(k), w.mrow, (size_t)B * P * MROW))) return rc;
-        }
-        m.wimg = reinterpret_cast<const bf16x8*>(d.wimg);
-        m.consts = d.consts;
-        if (k + 1 < nb) {
-            m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[k + 1].wv_lo);
-            if ((rc = launch_main<MODE_MID>(h, m, K_MAIN))) return rc;
-        } else {
-            m.wv_lo = nullptr;
-            if ((rc = launch_main<MODE_LAST>(h, m, K_MAIN))) return rc;
-        }
-        if (h->debug_keep && (rc = save_tap(h, "x" + std::to_string(k + 1), w.x, ntok * 64))) return rc;
+// block k given the (already reduced) row statistics in `srow`
+int phase_block(pf_handle* h, const ShardRun& r, int k, const float* srow) {
+    const BlockDev& d = h->blk[k];
+    const Workspace& w = r.w;
+    const int B = r.B, P = r.P, Lloc = r.Lloc;
+    int rc;
+    if (h->debug_keep && (rc = save_tap(h, "srow" + std::to_string(k), srow, (size_t)B * P * SROW))) return rc;
+    {
+        RowFinArgs a{srow, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag), d.row_woT, d.row_bv, d.row_bo, B * P, (float)r.L_total};
+        ProfScope ps(h, K_ROWFIN);
+        hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
+        HIPCHK(h, hipGetLastError());
     }
-    return allreduce(h, d_out, (size_t)B * P);
+    {
+        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 3) / 4};
+        ProfScope ps(h, K_COLSTATS);
+        hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+        HIPCHK(h, hipGetLastError());
+    }
+    {
+        ColFinArgs a{w.part, w.ctx, d.col_wvT, d.col_bv, B, Lloc, w.G, (float)P};
+        ProfScope ps(h, K_COLFIN);
+        hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(256), 0, h->stream, a);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (h->debug_keep) {
+        if ((rc = save_tap(h, "ctx" + std::to_string(k), w.ctx, (size_t)B * Lloc * 64))) return rc;
+        if ((rc = save_tap(h, "mrow" + std::to_string(k), w.mrow, (size_t)B * P * MROW))) return rc;
+    }
+    MainArgs m = main_args(h, r);
+    m.wimg = reinterpret_cast<const bf16x8*>(d.wimg);
+    m.consts = d.consts;
+    if (k + 1 < h->n_blocks) {
+        m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[k + 1].wv_lo);
+        if ((rc = launch_main<MODE_MID>(h, m, K_MAIN))) return rc;
+    } else {
+        m.wv_lo = nullptr;
+        if ((rc = launch_main<MODE_LAST>(h, m, K_MAIN))) return rc;
+    }
+    if (h->debug_keep && (rc = save_tap(h, "x" + std::to_string(k + 1), w.x, (size_t)B * P * Lloc * 64))) return rc;
+    return PF_OK;
+}
+
+// one batch chunk, everything resident on the device
+int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, int L_total, float* d_out) {
+    ShardRun r{};
+    r.d_idx = d_idx; r.d_out = d_out; r.B = B; r.N = N; r.P = N * (N - 1) / 2; r.Lloc = Lloc; r.L_total = L_total;
+    int rc = ensure_workspace(h, B, r.P, Lloc, &r.w);
+    if (rc) return rc;
+    if ((rc = ensure_pairs(h, N))) return rc;
+    if ((rc = phase_first(h, r))) return rc;
+    for (int k = 0; k < h->n_blocks; ++k) {
+        if ((rc = allreduce(h, r.w.srow, (size_t)B * r.P * SROW))) return rc;   // site-sharded runs only
+        if ((rc = phase_block(h, r, k, r.w.srow))) return rc;
+    }
+    return allreduce(h, d_out, (size_t)B * r.P);
 }
 
 int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
@@ -574,6 +600,21 @@ int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
 int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_begin, int l_end,
                         int L_total, float* d_out) {
     const int Lloc = l_end - l_begin;
+    if (h && Lloc == 0 && h->world > 1 && B >= 1 && N >= 2 && L_total >= 1) {
+        // a rank that owns no sites (L_total < world) still joins every collective with zeros
+        HIPCHK(h, hipSetDevice(h->device));
+        const int P0 = N * (N - 1) / 2;
+        Workspace w0;
+        int rc0 = ensure_workspace(h, B, P0, 1, &w0);
+        if (rc0) return rc0;
+        const size_t ns = (size_t)B * P0 * SROW;
+        for (int k = 0; k < h->n_blocks; ++k) {
+            HIPCHK(h, hipMemsetAsync(w0.srow, 0, ns * sizeof(float), h->stream));
+            if ((rc0 = allreduce(h, w0.srow, ns))) return rc0;
+        }
+        HIPCHK(h, hipMemsetAsync(d_out, 0, (size_t)B * P0 * sizeof(float), h->stream));
+        return allreduce(h, d_out, (size_t)B * P0);
+    }
     int rc = check_dims(h, B, N, Lloc, L_total);
     if (rc) return rc;
     if (l_begin < 0 || l_end > L_total) return fail(h, PF_EINVAL, "site range [%d, %d) outside [0, %d)", l_begin, l_end, L_total);
@@ -591,18 +632,18 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
 int forward_host_impl(pf_handle* h, const uint8_t* idx, int B, int N, int l_begin, int l_end,
                       int L_total, float* out) {
     const int Lloc = l_end - l_begin;
-    int rc = check_dims(h, B, N, Lloc, L_total);
+    int rc = (Lloc == 0 && h->world > 1) ? PF_OK : check_dims(h, B, N, Lloc, L_total);
     if (rc) return rc;
-    if (!idx || !out) return fail(h, PF_EINVAL, "null buffer");
+    if (!out || (!idx && Lloc > 0)) return fail(h, PF_EINVAL, "null buffer");
     const size_t nidx = (size_t)B * N * Lloc;
     for (size_t i = 0; i < nidx; ++i)
         if (idx[i] >= NA) return fail(h, PF_EINVAL, "residue index %d at offset %zu is outside 0..21", (int)idx[i], i);
     HIPCHK(h, hipSetDevice(h->device));
     const int P = N * (N - 1) / 2;
-    if (nidx > h->d_idx_bytes) {
+    if (nidx > h->d_idx_bytes || !h->d_idx) {
         if (h->d_idx) hipFree(h->d_idx);
         h->d_idx = nullptr; h->d_idx_bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_idx, nidx));
+        HIPCHK(h, hipMalloc((void**)&h->d_idx, nidx ? nidx : 1));
         h->d_idx_bytes = nidx;
     }
     const size_t nout = (size_t)B * P * sizeof(float);
@@ -612,7 +653,7 @@ int forward_host_impl(pf_handle* h, const uint8_t* idx, int B, int N, int l_begi
         HIPCHK(h, hipMalloc((void**)&h->d_out, nout));
         h->d_out_bytes = nout;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_idx, idx, nidx, hipMemcpyHostToDevice, h->stream));
+    if (nidx) HIPCHK(h, hipMemcpyAsync(h->d_idx, idx, nidx, hipMemcpyHostToDevice, h->stream));
     rc = forward_device_impl(h, h->d_idx, B, N, l_begin, l_end, L_total, h->d_out);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(out, h->d_out, nout, hipMemcpyDeviceToHost, h->stream));
@@ -832,6 +873,72 @@ int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_
     if (cu_count) *cu_count = h->prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = h->prop.totalGlobalMem;
     return PF_OK;
+}
+
+// Single-GPU emulation of the site-sharded forward ("fake backend" for tests): the alignment's
+// sites are split into `nshards` ranges exactly as phyloformer_amd/dist.py::site_range does, every
+// shard gets its own workspace and runs the same kernels as a real rank, and the two collectives
+// are replaced by a device-side sum over the shards' buffers.  idx: host uint8 [B][N][L].
+int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t L,
+                               int32_t nshards, float* out) {
+    if (!h) return PF_EINVAL;
+    int rc = check_dims(h, B, N, L, L);
+    if (rc) return rc;
+    if (nshards < 1 || nshards > 64 || !idx || !out) return fail(h, PF_EINVAL, "bad shard count or null buffer");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = ensure_pairs(h, N))) return rc;
+    const int P = N * (N - 1) / 2;
+    const int step = (L + nshards - 1) / nshards;
+    std::vector<ShardRun> runs;
+    std::vector<void*> allocs;
+    auto cleanup = [&]() { hipStreamSynchronize(h->stream); for (void* p : allocs) hipFree(p); };
+    for (int sidx = 0; sidx < nshards; ++sidx) {
+        const int lo = std::min(sidx * step, (int)L), hi = std::min((sidx + 1) * step, (int)L);
+        if (hi <= lo) continue;   // an empty rank contributes zeros to both sums
+        ShardRun r{};
+        r.B = B; r.N = N; r.P = P; r.Lloc = hi - lo; r.L_total = L;
+        size_t off[8];
+        r.w.G = colstats_groups(B, P, r.Lloc);
+        const size_t need = workspace_bytes(B, P, r.Lloc, r.w.G, off);
+        char* ws = nullptr; uint8_t* di = nullptr; float* dout = nullptr;
+        hipError_t e1 = hipMalloc((void**)&ws, need), e2 = hipMalloc((void**)&di, (size_t)B * N * r.Lloc),
+                   e3 = hipMalloc((void**)&dout, (size_t)B * P * sizeof(float));
+        if (ws) allocs.push_back(ws); if (di) allocs.push_back(di); if (dout) allocs.push_back(dout);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { cleanup(); return fail(h, PF_ENOMEM, "shard workspace allocation failed"); }
+        r.w.x = (float*)(ws + off[0]); r.w.qrow = (float*)(ws + off[1]); r.w.qcol = (float*)(ws + off[2]);
+        r.w.srow = (float*)(ws + off[3]); r.w.mrow = (float*)(ws + off[4]); r.w.part = (float*)(ws + off[5]);
+        r.w.ctx = (float*)(ws + off[6]); r.w.mfrag = (float*)(ws + off[7]);
+        std::vector<uint8_t> local((size_t)B * N * r.Lloc);
+        for (int b = 0; b < B; ++b)
+            for (int n = 0; n < N; ++n)
+                std::memcpy(&local[((size_t)b * N + n) * r.Lloc], &idx[((size_t)b * N + n) * L + lo], r.Lloc);
+        if (hipMemcpy(di, local.data(), local.size(), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(h, PF_EHIP, "idx upload failed"); }
+        r.d_idx = di; r.d_out = dout;
+        runs.push_back(r);
+    }
+    const bool keep = h->debug_keep;
+    h->debug_keep = false;
+    auto sum_into_first = [&](size_t count, bool is_out) {
+        for (size_t i = 1; i < runs.size(); ++i) {
+            float* dst = is_out ? runs[0].d_out : runs[0].w.srow;
+            const float* src = is_out ? runs[i].d_out : runs[i].w.srow;
+            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, dst, src, count);
+        }
+    };
+    for (auto& r : runs) if ((rc = phase_first(h, r))) break;
+    for (int k = 0; !rc && k < h->n_blocks; ++k) {
+        sum_into_first((size_t)B * P * SROW, false);               // stands in for all-reduce #k
+        for (auto& r : runs) if ((rc = phase_block(h, r, k, runs[0].w.srow))) break;
+    }
+    if (!rc) {
+        sum_into_first((size_t)B * P, true);                       // final all-reduce of the site sums
+        if (hipMemcpyAsync(out, runs[0].d_out, (size_t)B * P * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            rc = fail(h, PF_EHIP, "result copy failed");
+    }
+    h->debug_keep = keep;
+    cleanup();
+    return rc;
 }
 
 // Hardware-layout self test (see k_selftest); out must hold 2304 floats.

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pf_device_info": (C.c_int, [_H, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_uint64)]),
     "pf_selftest": (C.c_int, [_H, C.c_void_p]),
+    "pf_forward_shards_emulated": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -179,6 +181,18 @@ class Engine:
         out = np.empty((B, N * (N - 1) // 2), dtype=np.float32)
         self._check(self._lib.pf_forward_sharded(self._h, idx.ctypes.data, B, N, l_begin, l_end,
                                                  L_total, out.ctypes.data))
+        return out[0] if single else out
+
+    def forward_shards_emulated(self, idx: np.ndarray, nshards: int) -> np.ndarray:
+        """Site-sharded algorithm over ``nshards`` emulated ranks on this one GPU (tests)."""
+        idx = _u8(idx)
+        single = idx.ndim == 2
+        if single:
+            idx = idx[None]
+        B, N, L = idx.shape
+        out = np.empty((B, N * (N - 1) // 2), dtype=np.float32)
+        self._check(self._lib.pf_forward_shards_emulated(self._h, idx.ctypes.data, B, N, L, nshards,
+                                                         out.ctypes.data))
         return out[0] if single else out
 
     # -- device-resident variant (benchmark) ------------------------------------------------
