@@ -56,12 +56,27 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(tokens_per_launch):
+    """HBM bytes per k_main launch from the committed PMC passes (profiles/pmc_k_main.json, written by
+    tools/pmc.sh on the GPU box: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units,
+    FETCH_SIZE doubled for 16-byte-per-lane streaming reads as MI355X_MICROARCH.md prescribes),
+    scaled by tokens if the profiled batch differed.  None if no PMC file is present."""
+    path = os.path.join(REPO, "profiles", "pmc_k_main.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        p = json.load(fh)
+    return round(p["hbm_bytes_per_token"] * tokens_per_launch)
+
+
 def cpu_baseline(w, n_seqs, n_sites):
     """Reference-op-order torch port on the host cores: 1 warm-up (small) + 1 timed forward."""
     import torch
     from oracle import pf_oracle_torch
     from phyloformer_amd.msa_sim import simulate_batch
-    cores = os.cpu_count() or 1
+    # 32 threads: the fastest of 16/32/64/256 on the 2 x 64-core GPU host (9.9 s vs 59.6 s with all
+    # 256 hardware threads, where the OpenMP pool oversubscribes) - tools/cpu_threads.py
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     pf_oracle_torch.forward(w.tensors, simulate_batch(1, 20, 100, seed=9)[0])   # thread-pool warm-up
     idx = simulate_batch(1, n_seqs, n_sites, seed=3)[0]
@@ -169,7 +184,8 @@ def main():
             ach = flops / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": "k_main", "achieved": round(ach, 2),
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                    "traffic": pmc_traffic(tokens_per_launch),
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_main,
                     "note": "algorithmic flops (1 pass); the split-bf16 scheme issues 3 MFMA passes, "
                             "so frac tops out at 1/3"}
