@@ -94,9 +94,10 @@ const char* pf_last_error(const pf_handle_t* h);
 
 /* Options (before or between forwards):
  *   "max_seqs"   int   sequence cap, default 200 (model.py:39); 0 lifts it
- *   "gemm"       int   0 = split-bf16 x3 MFMA (default), 1 = exact fp32 MFMA
  *   "profile"    int   1 = bracket every launch with HIP events (see pf_profile_*)
  *   "debug_keep" int   1 = keep per-layer activations for pf_debug_read
+ *   "force_rccl" int   1 = pf_comm_init creates a real RCCL communicator even for one rank (tests)
+ *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)
  */
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
 

@@ -167,6 +167,7 @@ struct pf_handle {
     bool profile = false;
     bool debug_keep = false;
     int ablate = 0;
+    bool force_rccl = false;  // tests: create a real 1-rank communicator and run the collectives
     int64_t ws_limit_bytes = (int64_t)24 << 30;  // per-chunk workspace budget
     // weights
     float* table = nullptr;       // [22][64]
@@ -464,7 +465,7 @@ int save_tap(pf_handle* h, const std::string& name, const float* dptr, size_t n)
 }
 
 int allreduce(pf_handle* h, float* buf, size_t count) {
-    if (h->world <= 1) return PF_OK;
+    if (h->world <= 1 && !h->comm) return PF_OK;
     if (!h->comm) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
     ProfScope ps(h, K_ALLREDUCE);
     int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, h->comm, h->stream);
@@ -739,6 +740,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "profile") { drain_profile(h); h->profile = value != 0; }
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "ablate") h->ablate = (int)value;
+    else if (k == "force_rccl") h->force_rccl = value != 0;
     else if (k == "ws_limit_mb") h->ws_limit_bytes = value << 20;
     else return fail(h, PF_EINVAL, "unknown option '%s'", key);
     return PF_OK;
@@ -780,7 +782,7 @@ int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t wo
     if (h->comm) return fail(h, PF_ESTATE, "communicator already initialised");
     h->rank = rank;
     h->world = world_size;
-    if (world_size == 1) return PF_OK;
+    if (world_size == 1 && !h->force_rccl) return PF_OK;
     if (!unique_id) return fail(h, PF_EINVAL, "null unique id");
     std::string err;
     if (!load_rccl(err)) return fail(h, PF_ERCCL, "%s", err.c_str());

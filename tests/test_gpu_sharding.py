@@ -40,3 +40,22 @@ def test_config4_60x2000_eight_shards(engines, repo):
     err = np.abs(got - g["c4_dist"]).max()
     print(f"60x2000 over 8 emulated ranks: max-abs error vs reference {err:.3e}")
     assert err <= 1e-4
+
+
+def test_rccl_single_rank_communicator(weights, golden):
+    """dlopen(librccl), ncclGetUniqueId/CommInitRank/AllReduce on the engine's stream with one rank:
+    the 7 collectives of a sharded forward must leave the result unchanged."""
+    from phyloformer_amd.engine import Engine
+    g = golden("configs.npz")
+    a = g["c2_idx"][:2]
+    with Engine(weights("pf"), 0) as e:
+        ref = e.forward(a)
+        e.set_option("force_rccl", 1)
+        e.comm_init(e.unique_id(), 0, 1)
+        e.set_option("profile", 1)
+        e.profile_reset()
+        got = e.forward_sharded(a, 0, 200, 200)
+        n, _ms = e.profile_get("allreduce")
+        e.comm_destroy()
+    assert n == 7
+    assert np.array_equal(got, ref)
