@@ -633,8 +633,17 @@ constexpr int CPART = 4 * 64 + 8;
 // group's pairs.  Lanes: site = lane >> 4, channels 4*(lane & 15) .. +3, so one
 // wave-load is 1 KB contiguous.  Applies the row attention on the fly (it is not
 // materialised in HBM), then LayerNorm -> q', k' -> Z~ += k' x~.
+__device__ __forceinline__ float elu1_fast(float v) {
+    // elu(v) + 1 with the hardware exp2 (about 1 ulp): v > 0 ? v + 1 : exp(v)
+    return v > 0.f ? v + 1.f : __builtin_amdgcn_exp2f(v * 1.44269504088896340736f);
+}
+template <int PAT>
+__device__ __forceinline__ float swz(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PAT));
+}
+
 __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
-    __shared__ float red[4][64][25];
+    __shared__ float red[4][64][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane >> 4, cl = lane & 15;
     int bid = blockIdx.x;
@@ -647,21 +656,24 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     const int per = (a.P + a.G - 1) / a.G;
     const int p0 = g * per, p1 = min(a.P, p0 + per);
 
-    float w[8][4], bq[8];
+    float w[8][4];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(a.wqk + o * 64 + 4 * cl);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[o][i] = u[i];
-        bq[o] = a.bqk[o];
     }
-    float z[4][4], sq[4], sk[4];
+    // After the transposing reduction below lane cl holds projection j = cl >> 1
+    // (j < 4: q'[j], else k'[j - 4]); lanes cl and cl ^ 1 hold the same value.
+    const int j = cl >> 1;
+    const float bj = a.bqk[j];
+    const bool up3 = (cl & 8) != 0, up2 = (cl & 4) != 0, up1 = (cl & 2) != 0;
+    const float vmask = lvalid ? 1.f : 0.f;
+    float z[4][4], s_acc = 0.f;
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
-        sq[hh] = 0.f; sk[hh] = 0.f;
+    for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
         for (int i = 0; i < 4; ++i) z[hh][i] = 0.f;
-    }
 
     for (int p = p0 + wave; p < p1; p += 4) {
         const size_t pr = (size_t)b * a.P + p;
@@ -680,44 +692,53 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
         // x' = x + row attention of this block (bias row included)
 #pragma unroll
         for (int i = 0; i < 4; ++i) xr[i] = xv[i] + y[i];
-        float s = xr[0] + xr[1] + xr[2] + xr[3];
-        const float mean = row16_sum(s) * (1.f / 64.f);
+        const float mean = row16_sum((xr[0] + xr[1]) + (xr[2] + xr[3])) * (1.f / 64.f);
         float d[4], v = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { d[i] = xr[i] - mean; v = fmaf(d[i], d[i], v); }
-        const float rstd = 1.0f / sqrtf(row16_sum(v) * (1.f / 64.f) + LN_EPS);
+        const float rstd = __builtin_amdgcn_rsqf(row16_sum(v) * (1.f / 64.f) + LN_EPS);
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] *= rstd;
-        float qk[8];
+        // eight 64-long dot products: 4 channels per lane, then a transposing butterfly over the
+        // 16 lanes of the token (row_mirror, row_half_mirror, quad reverse, xor 1): 22 VALU
+        // instead of 32 DPP adds + 8 activations per lane
+        float pv[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            float acc = 0.f;
+        for (int o = 0; o < 8; ++o) pv[o] = fmaf(w[o][3], d[3], fmaf(w[o][2], d[2], fmaf(w[o][1], d[1], w[o][0] * d[0])));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = fmaf(w[o][i], d[i], acc);
-            qk[o] = elu1_acc(row16_sum(acc) + bq[o]);
+        for (int i = 0; i < 4; ++i) {
+            const float send = up3 ? pv[i] : pv[i + 4], keep = up3 ? pv[i + 4] : pv[i];
+            pv[i] = keep + dpp_f<0x140>(send);
         }
-        if (lvalid) {
-            if (cl == 0) {
-                f32x4 qs = {qk[0], qk[1], qk[2], qk[3]};
-                *reinterpret_cast<f32x4*>(a.qcol + tok * 4) = qs;
-            }
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
-                sq[hh] += qk[hh];
-                sk[hh] += qk[4 + hh];
+        for (int i = 0; i < 2; ++i) {
+            const float send = up2 ? pv[i] : pv[i + 2], keep = up2 ? pv[i + 2] : pv[i];
+            pv[i] = keep + dpp_f<0x141>(send);
+        }
+        {
+            const float send = up1 ? pv[0] : pv[1], keep = up1 ? pv[1] : pv[0];
+            pv[0] = keep + dpp_f<0x1B>(send);
+        }
+        const float act = elu1_fast(pv[0] + dpp_f<0xB1>(pv[0]) + bj) * vmask;   // q'[j] or k'[j-4]
+        s_acc += act;
+        if (lvalid && cl < 8 && (cl & 1) == 0) a.qcol[tok * 4 + j] = act;
+        // k'[hh] sits in lanes 8 + 2 hh (and +1) of this token's 16-lane row
+        const float k0 = swz<((8 + 0) << 5) | 0x10>(act), k1 = swz<((8 + 2) << 5) | 0x10>(act),
+                    k2 = swz<((8 + 4) << 5) | 0x10>(act), k3 = swz<((8 + 6) << 5) | 0x10>(act);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) z[hh][i] = fmaf(qk[4 + hh], d[i], z[hh][i]);
-            }
+        for (int i = 0; i < 4; ++i) {
+            z[0][i] = fmaf(k0, d[i], z[0][i]);
+            z[1][i] = fmaf(k1, d[i], z[1][i]);
+            z[2][i] = fmaf(k2, d[i], z[2][i]);
+            z[3][i] = fmaf(k3, d[i], z[3][i]);
         }
     }
     // cross-wave reduction through LDS, then one partial per (b, g, site)
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
+    for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[wave][lane][hh * 4 + i] = z[hh][i];
-        red[wave][lane][16 + hh] = sq[hh];
-        red[wave][lane][20 + hh] = sk[hh];
-    }
+    red[wave][lane][16] = s_acc;
     __syncthreads();
     if (wave == 0 && lvalid) {
         float* out = a.part + (((size_t)b * a.G + g) * a.Lloc + l) * CPART;
@@ -730,12 +751,8 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
                        red[2][lane][hh * 4 + i] + red[3][lane][hh * 4 + i];
             *reinterpret_cast<f32x4*>(out + hh * 64 + 4 * cl) = u;
         }
-        if (cl == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                out[256 + k] = red[0][lane][16 + k] + red[1][lane][16 + k] +
-                               red[2][lane][16 + k] + red[3][lane][16 + k];
-        }
+        if ((cl & 1) == 0)   // S_q[0..3] | S_k[0..3]
+            out[256 + j] = red[0][lane][16] + red[1][lane][16] + red[2][lane][16] + red[3][lane][16];
     }
 }
 
