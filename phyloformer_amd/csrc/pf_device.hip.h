@@ -109,26 +109,38 @@ __device__ __forceinline__ float swz_xor(float v) {
 // Transposing reduction: every lane holds 32 partial values v[j]; afterwards lane t (of each half)
 // holds sum over the half's 32 lanes of v[t].  31 shuffles instead of 160 for 32 all-reduces, and
 // the running statistics need one register per lane instead of 32.
-template <int M>
+template <int M, int DPP_CTRL>
 __device__ __forceinline__ void treduce_step(float* v, int t) {
+    // exchange partner: lane ^ 16 through the LDS crossbar (DPP_CTRL == 0), otherwise a DPP row
+    // pairing that flips bit log2(M) of the lane: row_mirror (8), row_half_mirror (4), quad reverse
+    // (2), quad xor 1 (1) - VALU-only, no LDS round trip
     const bool up = (t & M) != 0;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const float send = up ? v[i] : v[i + M];
         const float keep = up ? v[i + M] : v[i];
-        v[i] = keep + swz_xor<M>(send);
+        v[i] = keep + (DPP_CTRL ? dpp_f<DPP_CTRL>(send) : swz_xor<16>(send));
     }
 }
 __device__ __forceinline__ float treduce32(float (&v)[32], int t) {
-    treduce_step<16>(v, t);
-    treduce_step<8>(v, t);
-    treduce_step<4>(v, t);
-    treduce_step<2>(v, t);
-    treduce_step<1>(v, t);
+    treduce_step<16, 0>(v, t);
+    treduce_step<8, 0x140>(v, t);
+    treduce_step<4, 0x141>(v, t);
+    treduce_step<2, 0x1B>(v, t);
+    treduce_step<1, 0xB1>(v, t);
     return v[0];
 }
 
 // ---- numerics ---------------------------------------------------------------------------
+__device__ __forceinline__ float elu1_fast(float v) {
+    // elu(v) + 1 with the hardware exp2 (about 1 ulp): v > 0 ? v + 1 : exp(v)
+    return v > 0.f ? v + 1.f : __builtin_amdgcn_exp2f(v * 1.44269504088896340736f);
+}
+template <int PAT>
+__device__ __forceinline__ float swz(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PAT));
+}
+
 __device__ __forceinline__ float elu1_acc(float v) { return v > 0.f ? v + 1.f : expf(v); }
 __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
@@ -158,34 +170,30 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // a^2 = log2(e)/2 (then exp(-h^2/2) = exp2(-(a h)^2) needs no multiply) and W2 carries 1/a;
 // the function returns a*gelu(h) as packed bf16 pairs:  hi = bf16(g), lo = bf16(g - hi).
 //   gelu(h) = h/2 + |h| (1/2 - 1/2 poly(t) exp(-h^2/2)),  t = 1/(1 + p|h|/sqrt2)      (A&S 7.1.26)
-// Written so that hipcc (with -fno-slp-vectorize) emits packed v_pk_fma/mul for the polynomial
-// and scalar VOP3 forms with free |x| / -x modifiers elsewhere: ~52 VALU cycles per value.
+// Scalar VOP3 forms with free |x| / -x modifiers; built with -fno-slp-vectorize so that hipcc does
+// not re-pack them into v_pk_* (see gelu_scaled).
 constexpr float GELU_ALPHA = 0.84932180028801904272f;   // sqrt(log2(e) / 2)
-__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {
+__device__ __forceinline__ float gelu_scaled(float x) {
+    // a*gelu(h) for x = a*h.  Plain (non-packed) fp32 ops only: on gfx950 v_pk_fma_f32 / v_pk_mul_f32
+    // do not overlap with another wave's MFMAs (measured: MFMA || v_pk_fma = sum of both, MFMA || v_fma
+    // = max), while v_fma / v_mul / v_exp / v_rcp / v_cvt do - tools/valu_bench.hip.
     const float C = 0.3275911f * 0.70710678118654752440f / GELU_ALPHA;
-    const float d0 = fmaf(fabsf(x0), C, 1.0f);
-    const float d1 = fmaf(fabsf(x1), C, 1.0f);
-    const f32x2 t = {__builtin_amdgcn_rcpf(d0), __builtin_amdgcn_rcpf(d1)};
-    const f32x2 x = {x0, x1};
-    const f32x2 s = x * x;
-    const f32x2 e = {__builtin_amdgcn_exp2f(-s[0]), __builtin_amdgcn_exp2f(-s[1])};
-    // coefficients carry the factor 1/2
-    const f32x2 a5 = {0.5f * 1.061405429f, 0.5f * 1.061405429f}, a4 = {0.5f * -1.453152027f, 0.5f * -1.453152027f},
-                a3 = {0.5f * 1.421413741f, 0.5f * 1.421413741f}, a2 = {0.5f * -0.284496736f, 0.5f * -0.284496736f},
-                a1 = {0.5f * 0.254829592f, 0.5f * 0.254829592f}, half = {0.5f, 0.5f};
-    f32x2 p = __builtin_elementwise_fma(a5, t, a4);
-    p = __builtin_elementwise_fma(p, t, a3);
-    p = __builtin_elementwise_fma(p, t, a2);
-    p = __builtin_elementwise_fma(p, t, a1);
-    const f32x2 pt = p * t;
-    const f32x2 w = __builtin_elementwise_fma(-pt, e, half);          // Phi(|h|) - 1/2
-    const f32x2 u = {fabsf(x0) * w[0], fabsf(x1) * w[1]};
-    const f32x2 g = __builtin_elementwise_fma(x, half, u);
-    const bf16x2 h2 = {(__bf16)g[0], (__bf16)g[1]};
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), C, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-(x * x));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float w = fmaf(-(p * t), e, 0.5f);          // Phi(|h|) - 1/2
+    return fmaf(x, 0.5f, fabsf(x) * w);
+}
+__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {
+    const float g0 = gelu_scaled(x0), g1 = gelu_scaled(x1);
+    const bf16x2 h2 = {(__bf16)g0, (__bf16)g1};
     const unsigned hb = __builtin_bit_cast(unsigned, h2);
-    const f32x2 f = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
-    const f32x2 r = g - f;
-    const bf16x2 l2 = {(__bf16)r[0], (__bf16)r[1]};
+    const float r0 = g0 - __uint_as_float(hb << 16);
+    const float r1 = g1 - __uint_as_float(hb & 0xffff0000u);
+    const bf16x2 l2 = {(__bf16)r0, (__bf16)r1};
     hi_out = hb;
     lo_out = __builtin_bit_cast(unsigned, l2);
 }
@@ -256,9 +264,11 @@ struct MainArgs {
     const int16_t* pair_i;  // [P]                                    (MODE_FIRST)
     const int16_t* pair_j;  // [P]
     int B, N, P, Lloc;
+    size_t trash_tok;       // token index of a 32-token scratch area behind x and qrow (masked lanes)
     int store_x_last;       // debug: MODE_LAST also writes x back
+    unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
     int ablate;             // perf experiments only (results invalid): 1 no x load, 2 no stores,
-                            // 4 no next-row phase, 8 no apply phase, 16 no FFN
+                            // 4 no next-row phase, 8 no apply phase, 16 no FFN (2 is unused now)
     float inv_L_total;
 };
 
@@ -311,6 +321,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     const int h = lane >> 5;
     const int ntiles = (a.Lloc + 31) >> 5;
     const int ntasks = a.B * a.P;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define PF_TICK(k) do { if (a.prof) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; } } while (0)
+    if (a.prof) tprev = __builtin_amdgcn_s_memtime();
     const bf16x8* w1p = lw + FRAG_W1 + lane;   // per-lane fragment bases: all later offsets are immediates
     const bf16x8* w2p = lw + FRAG_W2 + lane;
 
@@ -325,6 +338,21 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         float s_kv = 0.f, s_q[4], s_k[4], s_out = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s_q[i] = 0.f; s_k[i] = 0.f; }
+
+        // The next tile's residual rows and q' are requested when the FFN of the current tile starts
+        // (the residual lives in the GEMM2 accumulators from then on, see below) and land during
+        // its ~6 us of matrix work, so a tile never starts by waiting on HBM.
+        f32x4 px[8], pqr, pqc;
+        auto prefetch = [&](int tl) {
+            const int ll = min(tl * 32 + t, a.Lloc - 1);
+            const size_t tk = row0 + ll;
+            const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tk * 64 + 4 * h);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) px[g] = xp[2 * g];
+            pqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
+            pqc = *reinterpret_cast<const f32x4*>(a.qcol + tk * 4);
+        };
+        if (MODE != MODE_FIRST) prefetch(0);
 
         for (int tile = 0; tile < ntiles; ++tile) {
             const int l = tile * 32 + t;
@@ -346,25 +374,18 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] + w[i] : 0.f;
                 }
             } else {
-                const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tok * 64 + 4 * h);
-                if (a.ablate & 1) {
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) x[j] = 0.01f * (float)(j + t);
-                } else {
+                for (int g = 0; g < 8; ++g)
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        f32x4 u = xp[2 * g];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] : 0.f;
-                    }
-                }
+                    for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? px[g][i] : 0.f;
+                PF_TICK(0);
                 if (!(a.ablate & 8)) {
                     f32x16 ya[2];  // starts from the column out_proj bias
                     load_acc_bias(ya[0], lc + CONST_BOC, h);
                     load_acc_bias(ya[1], lc + CONST_BOC + 32, h);
                     // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
                     {
-                        const f32x4 qr = *reinterpret_cast<const f32x4*>(a.qrow + tok * 4);
+                        const f32x4 qr = pqr;
                         float v[8];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
@@ -382,13 +403,13 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     }
                     // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
                     {
-                        const f32x4 qc = *reinterpret_cast<const f32x4*>(a.qcol + tok * 4);
+                        const f32x4 qc = pqc;
                         const f32x4* cp = reinterpret_cast<const f32x4*>(
                             a.ctx + ((size_t)b * a.Lloc + lc_) * 64 + 4 * h);
                         float o[32];
 #pragma unroll
                         for (int g = 0; g < 8; ++g) {
-                            f32x4 u = cp[2 * g];
+                            const f32x4 u = cp[2 * g];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) o[4 * g + i] = u[i] * qc[g >> 1];
                         }
@@ -407,6 +428,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int j = 0; j < 32; ++j) x[j] += ya[j >> 4][j & 15];
                 }
 
+                PF_TICK(1);
                 // ---- feed-forward (model.py:101-104): x += W2 gelu(W1' x~ + b1') + b2
                 if (!(a.ablate & 16)) {
                     bf16x8 xb_hi[4], xb_lo[4];
@@ -416,9 +438,15 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 #pragma unroll
                         for (int s = 0; s < 4; ++s) split8(&xn[8 * s], xb_hi[s], xb_lo[s]);
                     }
+                    // GEMM2 accumulates straight onto the residual: oa = x + b2 + W2 g.  x's registers
+                    // are dead for the whole hidden loop and hold the next tile's prefetch instead.
                     f32x16 oa[2];
                     load_acc_bias(oa[0], lc + CONST_B2, h);
                     load_acc_bias(oa[1], lc + CONST_B2 + 32, h);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
+                    if (tile + 1 < ntiles) prefetch(tile + 1);
+                    PF_TICK(2);
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
                         f32x16 ha;
@@ -453,21 +481,32 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                             fh = nh; fl = nl;
                         }
                     }
+                    PF_TICK(3);
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) x[j] += oa[j >> 4][j & 15];
+                    for (int j = 0; j < 32; ++j) x[j] = oa[j >> 4][j & 15];
                 }
             }
 
             if (MODE != MODE_LAST && !(a.ablate & 4)) {
                 // ---- statistics of the next block's row attention (attention.py:163-190)
-                if (valid && !(a.ablate & 2)) {
-                    f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
+                // Wv' lo fragments (L2) are requested before the residual store for the same reason
+                bf16x8 wl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wl[i] = a.wv_lo[i * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    // Branch-free store: a divergent `if (valid)` makes hipcc merge the vmcnt state of
+                    // both paths and wait for these stores (HBM write acks) at the first Wv' lo use.
+                    // Lanes past the end of the row write to a 32-token trash area behind x / qrow.
+                    const size_t stok = valid ? tok : a.trash_tok + t;
+                    f32x4* xo = reinterpret_cast<f32x4*>(a.x + stok * 64 + 4 * h);
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         f32x4 u = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
                         xo[2 * g] = u;
                     }
                 }
+                if (a.ablate & 32) continue;   // perf experiment: copy-only
                 f32x16 va[3];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -478,27 +517,31 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 {
                     float xn[32];
                     ln_pair(x, xn);
+                    bf16x8 xb_hi[4], xb_lo[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) split8(&xn[8 * s], xb_hi[s], xb_lo[s]);
+                    // q/k rows first (operands in LDS): the Wv' lo fragments requested above get the
+                    // LayerNorm, the split and these 12 MFMAs to arrive from L2
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        bf16x8 xb_hi, xb_lo;
-                        split8(&xn[8 * s], xb_hi, xb_lo);
-#pragma unroll
-                        for (int T = 0; T < 2; ++T) {
-                            const bf16x8 f_hi = lw[FRAG_WV + (T * 4 + s) * 64 + lane];
-                            const bf16x8 f_lo = a.wv_lo[(T * 4 + s) * 64 + lane];
-                            mfma3(va[T], f_hi, f_lo, xb_hi, xb_lo);
-                        }
                         bf16x8 q_hi = zero_frag(), q_lo = zero_frag();
                         if (t < 8) {
                             q_hi = lw[FRAG_QK + (s * 2) * 16 + h * 8 + t];
                             q_lo = lw[FRAG_QK + (s * 2 + 1) * 16 + h * 8 + t];
                         }
-                        mfma3(va[2], q_hi, q_lo, xb_hi, xb_lo);
+                        mfma3(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
                     }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int T = 0; T < 2; ++T) {
+                            const bf16x8 f_hi = lw[FRAG_WV + (T * 4 + s) * 64 + lane];
+                            mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
+                        }
                 }
                 float qk[4], ot[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qk[i] = elu1_acc(va[2][i]);
+                for (int i = 0; i < 4; ++i) qk[i] = elu1_fast(va[2][i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ot[i] = pair_other(qk[i], h);
                 float qn[4], kn[4];
@@ -508,18 +551,19 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     kn[i] = h ? qk[i] : ot[i];
                 }
                 {
+                    const float vm = valid ? 1.f : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { s_q[i] = fmaf(vm, qn[i], s_q[i]); s_k[i] = fmaf(vm, kn[i], s_k[i]); }
+                    // both half-waves hold the same q'; all lanes store (no branch, see above)
+                    const size_t stok = valid ? tok : a.trash_tok + t;
+                    f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
+                    *reinterpret_cast<f32x4*>(a.qrow + stok * 4) = qs;
+                }
+                {
                     float kv[32];
 #pragma unroll
                     for (int j = 0; j < 32; ++j) kv[j] = valid ? kn[j >> 3] * va[j >> 4][j & 15] : 0.f;
                     s_kv += treduce32(kv, t);
-                }
-                if (valid && !(a.ablate & 2)) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { s_q[i] += qn[i]; s_k[i] += kn[i]; }
-                    if (h == 0) {
-                        f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
-                        *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = qs;
-                    }
                 }
             } else if (MODE == MODE_LAST) {
                 // ---- head: softplus(w.x + b) summed over sites (model.py:182-185)
@@ -541,6 +585,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     }
                 }
             }
+            PF_TICK(4);
         }
 
         // ---- reduce over the 32 token lanes of each half-wave and publish ------------------
@@ -559,7 +604,13 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             s_out = half32_sum(s_out);
             if (lane == 0) a.out[task] = s_out * a.inv_L_total;
         }
+        PF_TICK(5);
     }
+    if (a.prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, tacc[k]);
+    }
+#undef PF_TICK
 }
 
 // ---- row finalisation: srow -> mrow ------------------------------------------------------
@@ -633,15 +684,6 @@ constexpr int CPART = 4 * 64 + 8;
 // group's pairs.  Lanes: site = lane >> 4, channels 4*(lane & 15) .. +3, so one
 // wave-load is 1 KB contiguous.  Applies the row attention on the fly (it is not
 // materialised in HBM), then LayerNorm -> q', k' -> Z~ += k' x~.
-__device__ __forceinline__ float elu1_fast(float v) {
-    // elu(v) + 1 with the hardware exp2 (about 1 ulp): v > 0 ? v + 1 : exp(v)
-    return v > 0.f ? v + 1.f : __builtin_amdgcn_exp2f(v * 1.44269504088896340736f);
-}
-template <int PAT>
-__device__ __forceinline__ float swz(float v) {
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PAT));
-}
-
 __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     __shared__ float red[4][64][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -167,6 +167,7 @@ struct pf_handle {
     bool profile = false;
     bool debug_keep = false;
     int ablate = 0;
+    unsigned long long* phase_prof = nullptr;  // device [8]: k_main per-phase cycle totals (experiments)
     bool force_rccl = false;  // tests: create a real 1-rank communicator and run the collectives
     int64_t ws_limit_bytes = (int64_t)24 << 30;  // per-chunk workspace budget
     // weights
@@ -401,8 +402,8 @@ int colstats_groups(int B, int P, int Lloc) {
 size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[8]) {
     const size_t tok = (size_t)B * P * Lloc;
     size_t o = 0;
-    off[0] = o; o = align_up(o + tok * 64 * 4, 256);                     // x
-    off[1] = o; o = align_up(o + tok * 4 * 4, 256);                      // qrow
+    off[0] = o; o = align_up(o + (tok + 32) * 64 * 4, 256);              // x (+ 32-token trash area)
+    off[1] = o; o = align_up(o + (tok + 32) * 4 * 4, 256);               // qrow (+ trash)
     off[2] = o; o = align_up(o + tok * 4 * 4, 256);                      // qcol
     off[3] = o; o = align_up(o + (size_t)B * P * SROW * 4, 256);         // srow
     off[4] = o; o = align_up(o + (size_t)B * P * MROW * 4, 256);         // mrow
@@ -506,7 +507,9 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
     m.out = r.d_out; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
     m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc; m.inv_L_total = 1.0f / (float)r.L_total;
     m.store_x_last = h->debug_keep ? 1 : 0;
+    m.trash_tok = (size_t)r.B * r.P * r.Lloc;
     m.ablate = h->ablate;
+    m.prof = h->phase_prof;
     return m;
 }
 
@@ -741,6 +744,11 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
+    else if (k == "phase_prof") {
+        if (value && !h->phase_prof) { HIPCHK(h, hipMalloc((void**)&h->phase_prof, 64)); h->owned.push_back(h->phase_prof); }
+        if (h->phase_prof) HIPCHK(h, hipMemset(h->phase_prof, 0, 64));
+        if (!value) h->phase_prof = nullptr;
+    }
     else if (k == "ws_limit_mb") h->ws_limit_bytes = value << 20;
     else return fail(h, PF_EINVAL, "unknown option '%s'", key);
     return PF_OK;
@@ -862,6 +870,14 @@ int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double
 
 int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap) {
     if (!h || !name) return PF_EINVAL;
+    if (std::strcmp(name, "phase_prof") == 0) {
+        if (!h->phase_prof) return fail(h, PF_ESTATE, "phase_prof not enabled");
+        unsigned long long v[8];
+        hipStreamSynchronize(h->stream);
+        if (hipMemcpy(v, h->phase_prof, 64, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, PF_EHIP, "phase_prof copy");
+        for (int i = 0; i < 8 && i < cap; ++i) dst[i] = (float)((double)v[i] * 1e-6);   // mega-cycles
+        return 8;
+    }
     auto it = h->taps.find(name);
     if (it == h->taps.end()) return fail(h, PF_ESTATE, "no tap '%s' (set debug_keep=1 and run a forward)", name);
     const int64_t n = (int64_t)it->second.size();

@@ -7,7 +7,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define REP8(x) x x x x x x x x
-template <int OP>
+template <int OP, int VK = 0>
 __global__ void k(float* out, int iters) {
     float a0 = threadIdx.x * 1e-3f + 1.f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b0 = 1.0001f, b1 = 0.9999f;
@@ -66,7 +66,22 @@ __global__ void k(float* out, int iters) {
                 REP8(acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
                      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0);) }
             }
-            if (OP == 11 || (OP == 10 && !mf)) {
+            if ((OP == 11 || (OP == 10 && !mf)) && VK == 1) {
+                if (OP == 11 && mf) {} else {
+                REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
+                                  "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));) }
+            } else if ((OP == 11 || (OP == 10 && !mf)) && VK == 2) {
+                if (OP == 11 && mf) {} else {
+                REP8(asm volatile("v_exp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_exp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                                  "v_exp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_exp_f32 %6, %6\n v_rcp_f32 %7, %7\n v_exp_f32 %0, %0\n v_rcp_f32 %1, %1\n"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+            } else if ((OP == 11 || (OP == 10 && !mf)) && VK == 3) {
+                if (OP == 11 && mf) {} else {
+                REP8(asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1\n v_and_b32 %1, %1, %8\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_lshlrev_b32 %3, 16, %3\n"
+                                  "v_cvt_pk_bf16_f32 %4, %4, %5\n v_and_b32 %5, %5, %8\n v_cvt_pk_bf16_f32 %6, %6, %7\n v_lshlrev_b32 %7, 16, %7\n v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %9\n"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));) }
+            } else if (OP == 11 || (OP == 10 && !mf)) {
                 if (OP == 11 && mf) {} else {
                 REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                                   "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
@@ -84,13 +99,13 @@ __global__ void k(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int OP>
+template <int OP, int VK = 0>
 void run(const char* name, int threads, int per_iter, float* out) {
     const int iters = 2000;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int r = 0; r < 2; ++r) {
         hipEventRecord(a);
-        hipLaunchKernelGGL(k<OP>, dim3(256), dim3(threads), 0, 0, out, iters);
+        hipLaunchKernelGGL((k<OP, VK>), dim3(256), dim3(threads), 0, 0, out, iters);
         hipEventRecord(b); hipEventSynchronize(b);
     }
     float ms; hipEventElapsedTime(&ms, a, b);
@@ -118,5 +133,11 @@ int main() {
     run<12>("only waves0-3: 16 mfma/iter", 512, 1, out);
     run<11>("only waves4-7: 80 v_fma/iter", 512, 1, out);
     run<10>("both concurrently", 512, 1, out);
+    run<11, 1>("only waves4-7: 80 v_pk_fma/iter", 512, 1, out);
+    run<10, 1>("mfma + pk_fma concurrently", 512, 1, out);
+    run<11, 2>("only waves4-7: 80 exp/rcp per iter", 512, 1, out);
+    run<10, 2>("mfma + exp/rcp concurrently", 512, 1, out);
+    run<11, 3>("only waves4-7: 80 cvt/and/lshl per iter", 512, 1, out);
+    run<10, 3>("mfma + cvt/logic concurrently", 512, 1, out);
     return 0;
 }
