@@ -94,7 +94,8 @@ const char* pf_last_error(const pf_handle_t* h);
 
 /* Options (before or between forwards):
  *   "max_seqs"   int   sequence cap, default 200 (model.py:39); 0 lifts it
- *   "profile"    int   1 = bracket every launch with HIP events (see pf_profile_*)
+ *   "profile"    int   1 = bracket every launch with HIP events (see pf_profile_*); 2 = only the
+ *                      dominant kernel k_main (event pairs serialise the stream: 1 costs ~15 %, 2 ~5 %)
  *   "debug_keep" int   1 = keep per-layer activations for pf_debug_read
  *   "force_rccl" int   1 = pf_comm_init creates a real RCCL communicator even for one rank (tests)
  *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)

@@ -165,6 +165,7 @@ struct pf_handle {
     // options
     int64_t max_seqs = 200;
     bool profile = false;
+    bool profile_main_only = false;  // "profile" = 2: bracket only k_main (the dominant kernel)
     bool debug_keep = false;
     int ablate = 0;
     unsigned long long* phase_prof = nullptr;  // device [8]: k_main per-phase cycle totals (experiments)
@@ -438,11 +439,13 @@ hipEvent_t get_event(pf_handle* h) {
 }
 struct ProfScope {
     pf_handle* h; int kid; hipEvent_t a{}, b{};
+    bool on;
     ProfScope(pf_handle* h_, int kid_) : h(h_), kid(kid_) {
-        if (h->profile) { a = get_event(h); b = get_event(h); hipEventRecord(a, h->stream); }
+        on = h->profile && (!h->profile_main_only || kid_ == K_MAIN);
+        if (on) { a = get_event(h); b = get_event(h); hipEventRecord(a, h->stream); }
     }
     ~ProfScope() {
-        if (h->profile) { hipEventRecord(b, h->stream); h->pending.push_back({kid, a, b}); }
+        if (on) { hipEventRecord(b, h->stream); h->pending.push_back({kid, a, b}); }
     }
 };
 void drain_profile(pf_handle* h) {
@@ -740,7 +743,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     if (!h || !key) return PF_EINVAL;
     const std::string k(key);
     if (k == "max_seqs") h->max_seqs = value;
-    else if (k == "profile") { drain_profile(h); h->profile = value != 0; }
+    else if (k == "profile") { drain_profile(h); h->profile = value != 0; h->profile_main_only = value == 2; }
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
