@@ -187,15 +187,28 @@ __device__ __forceinline__ float gelu_scaled(float x) {
     const float w = fmaf(-(p * t), e, 0.5f);          // Phi(|h|) - 1/2
     return fmaf(x, 0.5f, fabsf(x) * w);
 }
-__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {
-    const float g0 = gelu_scaled(x0), g1 = gelu_scaled(x1);
+// (g0, g1) -> packed bf16 pairs hi = bf16(g), lo = bf16(g - hi).  The residual g - hi comes from
+// v_dot2c_f32_bf16 (g += hi.lo * -1 + hi.hi * 0): one 4.5-cycle op instead of unpack (4.2) + subtract
+// (2.9), bit-identical to the fp32 subtraction (tools/dot2c_test.hip), and it overlaps with MFMA.
+__device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out, unsigned& lo_out) {
     const bf16x2 h2 = {(__bf16)g0, (__bf16)g1};
     const unsigned hb = __builtin_bit_cast(unsigned, h2);
-    const float r0 = g0 - __uint_as_float(hb << 16);
-    const float r1 = g1 - __uint_as_float(hb & 0xffff0000u);
+    float r0 = g0, r1 = g1;
+    // HAZARD (measured on gfx950, not interlocked): a VALU that reads the result of v_dot2c_f32_bf16
+    // needs >= 2 wait states after it (s_nop 0 gives wrong data, s_nop 1 is clean on every golden);
+    // hipcc pads nothing inside an asm statement, so the pad lives in the string, with one spare state.
+#ifndef PF_DOT2C_PRE
+#define PF_DOT2C_PRE ""
+#define PF_DOT2C_POST "\n\ts_nop 2"
+#endif
+    asm volatile(PF_DOT2C_PRE "v_dot2c_f32_bf16 %0, %2, %4\n\tv_dot2c_f32_bf16 %1, %3, %4" PF_DOT2C_POST
+                 : "+v"(r0), "+v"(r1) : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(hb));
     const bf16x2 l2 = {(__bf16)r0, (__bf16)r1};
     hi_out = hb;
     lo_out = __builtin_bit_cast(unsigned, l2);
+}
+__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {
+    split_pair(gelu_scaled(x0), gelu_scaled(x1), hi_out, lo_out);
 }
 // eight accumulator values acc[base .. base+7] -> one B-operand fragment pair
 __device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8& hi, bf16x8& lo) {
@@ -213,12 +226,16 @@ __device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8&
 
 // split 8 floats into bf16 hi + bf16 lo (x ~= hi + lo to 2^-17 relative)
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        __bf16 hh = (__bf16)v[i];
-        hi[i] = hh;
-        lo[i] = (__bf16)(v[i] - (float)hh);
+    for (int k = 0; k < 4; ++k) {
+        unsigned a, b;
+        split_pair(v[2 * k], v[2 * k + 1], a, b);
+        h[k] = a;
+        l[k] = b;
     }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
 }
 
 #define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)

@@ -611,23 +611,31 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
         // a rank that owns no sites (L_total < world) still joins every collective with zeros
         HIPCHK(h, hipSetDevice(h->device));
         const int P0 = N * (N - 1) / 2;
-        Workspace w0;
-        int rc0 = ensure_workspace(h, B, P0, 1, &w0);
-        if (rc0) return rc0;
-        const size_t ns = (size_t)B * P0 * SROW;
-        for (int k = 0; k < h->n_blocks; ++k) {
-            HIPCHK(h, hipMemsetAsync(w0.srow, 0, ns * sizeof(float), h->stream));
-            if ((rc0 = allreduce(h, w0.srow, ns))) return rc0;
+        const int cb0 = chunk_batch(h, B, P0, (L_total + h->world - 1) / h->world);   // same chunks as the peers
+        for (int b0 = 0; b0 < B; b0 += cb0) {
+            const int nb0 = std::min(cb0, B - b0);
+            Workspace w0;
+            int rc0 = ensure_workspace(h, nb0, P0, 1, &w0);
+            if (rc0) return rc0;
+            const size_t ns = (size_t)nb0 * P0 * SROW;
+            for (int k = 0; k < h->n_blocks; ++k) {
+                HIPCHK(h, hipMemsetAsync(w0.srow, 0, ns * sizeof(float), h->stream));
+                if ((rc0 = allreduce(h, w0.srow, ns))) return rc0;
+            }
+            HIPCHK(h, hipMemsetAsync(d_out + (size_t)b0 * P0, 0, (size_t)nb0 * P0 * sizeof(float), h->stream));
+            if ((rc0 = allreduce(h, d_out + (size_t)b0 * P0, (size_t)nb0 * P0))) return rc0;
         }
-        HIPCHK(h, hipMemsetAsync(d_out, 0, (size_t)B * P0 * sizeof(float), h->stream));
-        return allreduce(h, d_out, (size_t)B * P0);
+        return PF_OK;
     }
     int rc = check_dims(h, B, N, Lloc, L_total);
     if (rc) return rc;
     if (l_begin < 0 || l_end > L_total) return fail(h, PF_EINVAL, "site range [%d, %d) outside [0, %d)", l_begin, l_end, L_total);
     HIPCHK(h, hipSetDevice(h->device));
     const int P = N * (N - 1) / 2;
-    const int cb = chunk_batch(h, B, P, Lloc);
+    // every rank must cut the batch into the same chunks (one all-reduce sequence per chunk), so the
+    // chunk size is derived from the largest shard, not from this rank's own
+    const int Lmax = h->world > 1 ? (L_total + h->world - 1) / h->world : Lloc;
+    const int cb = chunk_batch(h, B, P, std::max(Lloc, Lmax));
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nbch = std::min(cb, B - b0);
         rc = forward_chunk(h, d_idx + (size_t)b0 * N * Lloc, nbch, N, Lloc, L_total, d_out + (size_t)b0 * P);
