@@ -45,6 +45,11 @@ constexpr float LN_EPS = 1e-5f;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// explicit LDS pointers: with an opaque per-lane base (PF_OPAQUE) every fragment / constant read
+// becomes `ds_read_b128 v, base offset:imm` instead of a v_add_u32 with a > 16-bit literal per read
+typedef const bf16x8 __attribute__((address_space(3)))* lds_frag_t;
+typedef const float __attribute__((address_space(3)))* lds_f32_t;
+#define PF_OPAQUE(p) asm volatile("" : "+v"(p))
 
 // LDS image of one block's MFMA A operands (bf16x8 fragments, 16 B per lane):
 //   W1' : [8 T][4 s][2 hi/lo][64 lanes]      64 KB   (FFN 64->256, LN affine folded)
@@ -185,7 +190,11 @@ __device__ __forceinline__ float gelu_scaled(float x) {
     p = fmaf(p, u, -0.637684925f);
     p = fmaf(p, u, -1.35494915f);
     p = fmaf(p, u, -1.00003762f);
-    return fmaf(-u, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
+    // fmaxf() would first canonicalise x (a second v_max x, x); the asm names p as an input only to
+    // stay behind the compiler-visible first reader of the MFMA result x (hazard padding)
+    float m;
+    asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x), "v"(p));
+    return fmaf(-u, __builtin_amdgcn_exp2f(p), m);
 }
 // (g0, g1) -> packed bf16 pairs hi = bf16(g), lo = bf16(g - hi).  The residual g - hi comes from
 // v_dot2c_f32_bf16 (g += hi.lo * -1 + hi.hi * 0): one 4.5-cycle op instead of unpack (4.2) + subtract
@@ -291,8 +300,19 @@ struct MainArgs {
 
 enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
 
-__device__ __forceinline__ void load_acc_bias(f32x16& acc, const float* lds_bias, int h) {
-    // acc[r] = bias[row(r, h)], row = 8*(r>>2) + 4*h + (r&3): four 16-byte LDS reads
+typedef const f32x4 __attribute__((address_space(3)))* lds_f32x4_t;
+__device__ __forceinline__ void load_acc_bias(f32x16& acc, lds_f32_t lds_bias_h) {
+    // acc[r] = bias[row(r, h)], row = 8*(r>>2) + 4*h + (r&3): four 16-byte LDS reads; the caller
+    // passes bias + 4*h
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 bb = *(lds_f32x4_t)(lds_bias_h + 8 * q4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q4 + i] = bb[i];
+    }
+}
+
+__device__ __forceinline__ void load_acc_bias(f32x16& acc, const float* lds_bias, int h) {   // tools/
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(lds_bias + 8 * q4 + 4 * h);
@@ -317,8 +337,8 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 template <int MODE>
 __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const bf16x8* lw = reinterpret_cast<const bf16x8*>(smem);
-    const float* lc = reinterpret_cast<const float*>(smem + FRAG_END * 16);
+    lds_frag_t lw = (lds_frag_t)smem;
+    lds_f32_t lc = (lds_f32_t)(smem + FRAG_END * 16);
 
     {
         uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -341,8 +361,13 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
 #define PF_TICK(k) do { if (a.prof) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; } } while (0)
     if (a.prof) tprev = __builtin_amdgcn_s_memtime();
-    const bf16x8* w1p = lw + FRAG_W1 + lane;   // per-lane fragment bases: all later offsets are immediates
-    const bf16x8* w2p = lw + FRAG_W2 + lane;
+    lds_frag_t w1p = lw + FRAG_W1 + lane;   // per-lane bases: all later offsets are immediates
+    lds_frag_t w2p = lw + FRAG_W2 + lane;
+    lds_frag_t wop = lw + FRAG_WO + lane;
+    lds_frag_t wvp = lw + FRAG_WV + lane;
+    lds_frag_t qkp = lw + FRAG_QK + h * 8 + (t & 7);
+    lds_f32_t lch = lc + 4 * h;
+    PF_OPAQUE(wop); PF_OPAQUE(wvp); PF_OPAQUE(qkp); PF_OPAQUE(lch);
 
     for (int task = blockIdx.x * MAIN_WAVES + wave; task < ntasks; task += gridDim.x * MAIN_WAVES) {
         const int b = task / a.P;
@@ -398,8 +423,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 PF_TICK(0);
                 if (!(a.ablate & 8)) {
                     f32x16 ya[2];  // starts from the column out_proj bias
-                    load_acc_bias(ya[0], lc + CONST_BOC, h);
-                    load_acc_bias(ya[1], lc + CONST_BOC + 32, h);
+                    load_acc_bias(ya[0], lch + CONST_BOC);
+                    load_acc_bias(ya[1], lch + CONST_BOC + 32);
                     // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
                     {
                         const f32x4 qr = pqr;
@@ -436,8 +461,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                             split8(&o[8 * s], ob_hi, ob_lo);
 #pragma unroll
                             for (int To = 0; To < 2; ++To) {
-                                const bf16x8* f = lw + FRAG_WO + ((To * 4 + s) * 2) * 64 + lane;
-                                mfma3(ya[To], f[0], f[64], ob_hi, ob_lo);
+                                lds_frag_t f = wop + ((To * 4 + s) * 2) * 64;
+                                const bf16x8 a_hi = f[0], a_lo = f[64];
+                                mfma3(ya[To], a_hi, a_lo, ob_hi, ob_lo);
                             }
                         }
                     }
@@ -458,8 +484,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     // GEMM2 accumulates straight onto the residual: oa = x + b2 + W2 g.  x's registers
                     // are dead for the whole hidden loop and hold the next tile's prefetch instead.
                     f32x16 oa[2];
-                    load_acc_bias(oa[0], lc + CONST_B2, h);
-                    load_acc_bias(oa[1], lc + CONST_B2 + 32, h);
+                    load_acc_bias(oa[0], lch + CONST_B2);
+                    load_acc_bias(oa[1], lch + CONST_B2 + 32);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
                     if (tile + 1 < ntiles) prefetch(tile + 1);
@@ -467,9 +493,11 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
                         f32x16 ha;
-                        load_acc_bias(ha, lc + CONST_B1 + 32 * T, h);
-                        const bf16x8* f1 = w1p + T * 512;
-                        const bf16x8* f2 = w2p + T * 256;
+                        lds_frag_t f1 = w1p + T * 512;
+                        lds_frag_t f2 = w2p + T * 256;
+                        lds_f32_t bp = lch + CONST_B1 + 32 * T;
+                        PF_OPAQUE(f1); PF_OPAQUE(f2); PF_OPAQUE(bp);
+                        load_acc_bias(ha, bp);
                         // software-pipelined fragment reads: the next step's A operands are in
                         // flight while the current step's three MFMAs issue
                         bf16x8 fh = f1[0], fl = f1[64];
@@ -543,8 +571,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int s = 0; s < 4; ++s) {
                         bf16x8 q_hi = zero_frag(), q_lo = zero_frag();
                         if (t < 8) {
-                            q_hi = lw[FRAG_QK + (s * 2) * 16 + h * 8 + t];
-                            q_lo = lw[FRAG_QK + (s * 2 + 1) * 16 + h * 8 + t];
+                            q_hi = qkp[(s * 2) * 16];
+                            q_lo = qkp[(s * 2 + 1) * 16];
                         }
                         mfma3(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
                     }
@@ -552,7 +580,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int T = 0; T < 2; ++T) {
-                            const bf16x8 f_hi = lw[FRAG_WV + (T * 4 + s) * 64 + lane];
+                            const bf16x8 f_hi = wvp[(T * 4 + s) * 64];
                             mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
                         }
                 }
@@ -587,7 +615,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 float z = 0.f;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(lc + CONST_HW + 8 * g + 4 * h);
+                    const f32x4 w4 = *(lds_f32x4_t)(lch + CONST_HW + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) z = fmaf(w4[i], x[4 * g + i], z);
                 }
