@@ -413,13 +413,16 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 for (int g = 0; g < 8; ++g) {
                     f32x4 u = ti[2 * g], w = tj[2 * g];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? u[i] + w[i] : 0.f;
+                    for (int i = 0; i < 4; ++i) x[4 * g + i] = u[i] + w[i];   // clamped site: finite
                 }
             } else {
+                // lanes past the end of the row hold a copy of the row's last site (clamped address):
+                // finite values, no masking needed - their statistics are multiplied by 0 and their
+                // stores go to the trash area
 #pragma unroll
                 for (int g = 0; g < 8; ++g)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[4 * g + i] = valid ? px[g][i] : 0.f;
+                    for (int i = 0; i < 4; ++i) x[4 * g + i] = px[g][i];
                 PF_TICK(0);
                 if (!(a.ablate & 8)) {
                     f32x16 ya[2];  // starts from the column out_proj bias
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 {
                     const float vm = valid ? 1.f : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { s_q[i] = fmaf(vm, qn[i], s_q[i]); s_k[i] = fmaf(vm, kn[i], s_k[i]); }
+                    for (int i = 0; i < 4; ++i) { kn[i] *= vm; s_q[i] = fmaf(vm, qn[i], s_q[i]); s_k[i] += kn[i]; }
                     // both half-waves hold the same q'; all lanes store (no branch, see above)
                     const size_t stok = valid ? tok : a.trash_tok + t;
                     f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
@@ -607,7 +610,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 {
                     float kv[32];
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) kv[j] = valid ? kn[j >> 3] * va[j >> 4][j & 15] : 0.f;
+                    for (int j = 0; j < 32; ++j) kv[j] = kn[j >> 3] * va[j >> 4][j & 15];   // kn is masked
                     s_kv += treduce32(kv, t);
                 }
             } else if (MODE == MODE_LAST) {
