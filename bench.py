@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--shard", choices=["sites", "alignments"], default="sites")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event bracketing of kernels")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="test aid: run the N>1 code path (gloo rendezvous, RCCL communicator, 7 all-reduces "
+                         "per step) even with one rank")
     return ap.parse_args()
 
 
@@ -104,14 +107,19 @@ def main():
     from phyloformer_amd import dist as pfdist
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     w = load_weights(args.ckpt)
     eng = Engine(w, device=local_rank)
-    if world > 1 and args.shard == "sites":
+    if args.force_dist and world == 1:
+        eng.set_option("force_rccl", 1)
+        uid = pfdist.broadcast_bytes(eng.unique_id(), 128, src=0)
+        eng.comm_init(uid, 0, 1)
+    elif world > 1 and args.shard == "sites":
         pfdist.init_engine_comm(eng)
 
     N, L = args.n_seqs, args.n_sites
