@@ -167,6 +167,34 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
  * checks them against the layout the kernels assume. */
 int pf_selftest(pf_handle_t* h, float* out);
 
+/* ---- host-side file formats of the CLI (no GPU, callable without a handle) --------------------
+ *
+ * pf_parse_fasta replaces load_alignment (phyloformer/data.py:11-31): `data[len]` is the whole file;
+ * lines are split on '\n' and stripped of ASCII white space, a line starting with '>' opens a record
+ * (id = rest of the line), other non-empty lines are residues of the current record.  Writes residue
+ * indices uint8 [N][L] to `idx` (NULL = only measure) and, per record, the (offset, length) of its id
+ * inside `data` to id_spans[2*N] (NULL = skip; at most max_seqs records).  Returns PF_OK and N, L, or
+ *   PF_FASTA_EBYTE     byte outside the alphabet, *detail = the byte   (KeyError, data.py:26)
+ *   PF_FASTA_ERAGGED   records of different lengths, *n_out still set  (ValueError from one_hot/stack)
+ *   PF_FASTA_ENOHEADER residues before the first '>'                   (IndexError, data.py:26)
+ *   PF_FASTA_EEMPTY    no record at all
+ *   PF_FASTA_ECAP      idx_cap or max_seqs too small
+ */
+#define PF_FASTA_EBYTE (-16)
+#define PF_FASTA_ERAGGED (-17)
+#define PF_FASTA_ENOHEADER (-18)
+#define PF_FASTA_EEMPTY (-19)
+#define PF_FASTA_ECAP (-20)
+int pf_parse_fasta(const char* data, int64_t len, uint8_t* idx, int64_t idx_cap, int64_t* id_spans,
+                   int32_t max_seqs, int32_t* n_out, int32_t* l_out, int64_t* detail);
+
+/* pf_format_phylip replaces vec_to_phylip (infer_alns.py:14-25): "N\n" then, per sequence,
+ * "<id> d0 d1 ... dN-1\n" with "%.10f" entries of the symmetrised matrix (zero diagonal).
+ * preds: float [N(N-1)/2], pairs (i<j) lexicographic; ids: N NUL-terminated strings.
+ * Returns the text length in bytes (not NUL-terminated); nothing past `cap` is written, so a
+ * first call with out = NULL, cap = 0 sizes the buffer. */
+int64_t pf_format_phylip(const float* preds, int32_t n, const char* const* ids, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,8 +10,13 @@ infer_alns.py:36-38,100-103) or the run aborts with ``ValueError``; for each
 alignment ``OUTDIR/<stem>.phy`` receives the PHYLIP distance matrix
 (``%.10f``) and, with ``-t``, ``OUTDIR/<stem>.nj.nwk`` a neighbour-joining tree.
 
-Additive flags (not in the reference): ``--device``, ``--batch`` (group
-same-shape alignments into one launch), ``--bench`` (print a JSON timing line).
+Additive flags (not in the reference): ``--device`` / ``--devices 0,1,...`` (one
+process per GPU, files sharded), ``--batch`` (same-shape alignments per launch;
+default: fill a token budget per shape), ``--io-threads``, ``--python-io``,
+``--bench`` (print a JSON timing line).  Scheduling lives in
+``phyloformer_amd/scheduler.py``: files are bucketed by shape, parsed ahead of the
+GPU and written behind it.  Unlike the reference, a non-FASTA entry aborts the run
+before the first forward instead of when the loop reaches it.
 The forward pass runs in ``libphyloformer_amd.so``; there is no CPU fallback.
 """
 import argparse
@@ -37,74 +42,87 @@ def build_parser():
     parser.add_argument("--trees", "-t", action="store_true",
                         help="Output NJ trees as well as matrices")
     parser.add_argument("--device", type=int, default=0, help="HIP device ordinal (default 0)")
-    parser.add_argument("--batch", type=int, default=1,
-                        help="max same-shape alignments per launch (default 1 = reference order)")
+    parser.add_argument("--devices", default=None,
+                        help="comma-separated HIP device ordinals: shard the files over these GPUs, "
+                             "one process per GPU (alignment-level data parallelism, no collective)")
+    parser.add_argument("--batch", type=int, default=0,
+                        help="same-shape alignments per launch; 0 (default) = fill a token budget per shape, "
+                             "1 = one alignment per launch as in the reference")
+    parser.add_argument("--io-threads", type=int, default=4, help="FASTA loader / PHYLIP writer threads")
+    parser.add_argument("--python-io", action="store_true",
+                        help="use the pure-Python FASTA parser and PHYLIP writer instead of the native ones")
+    parser.add_argument("--worker", default=None, help=argparse.SUPPRESS)   # "r/W": share r of W of the files
     parser.add_argument("--bench", action="store_true", help="print a JSON timing summary to stderr")
     return parser
 
 
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
 
-    from phyloformer_amd.fasta import load_alignment
-    from phyloformer_amd.model import Phyloformer
-    from phyloformer_amd.phylip import vec_to_phylip
-
-    try:
-        from tqdm import tqdm
-    except Exception:  # pragma: no cover
-        def tqdm(x, **_k):
-            return x
-
-    model = Phyloformer.from_checkpoint(args.weights, device=args.device)
-    model.eval()
+    from phyloformer_amd import scheduler
 
     in_dir = os.path.abspath(args.alndir)
     out_dir = os.path.abspath(args.outdir)  # TypeError if omitted, as in the reference (:90)
     os.makedirs(out_dir, exist_ok=True)
 
+    if args.devices and not args.worker:
+        devices = [int(d) for d in args.devices.split(",") if d.strip() != ""]
+        if len(devices) > 1:
+            t0 = time.perf_counter()
+            child_argv = [a for a in argv if a != "--bench"]
+            for flag in ("--devices", "--device"):
+                while flag in child_argv:
+                    k = child_argv.index(flag)
+                    del child_argv[k:k + 2]
+            child_argv = [a for a in child_argv if not a.startswith("--devices=") and not a.startswith("--device=")]
+            rc, reports = scheduler.run_multi_device(os.path.abspath(__file__), child_argv, devices)
+            if args.bench:
+                wall = time.perf_counter() - t0
+                n = sum(r["alignments"] for r in reports)
+                print(json.dumps({"alignments": n, "devices": devices, "wall_s_incl_startup": round(wall, 4),
+                                  "alignments_per_s": round(sum(r["alignments_per_s"] or 0 for r in reports), 3),
+                                  "workers": reports}), file=sys.stderr)
+            return rc
+        args.device = devices[0]
+
+    from phyloformer_amd.model import Phyloformer
+
+    try:
+        from tqdm import tqdm
+    except Exception:  # pragma: no cover
+        tqdm = None
+
+    t0 = time.perf_counter()
+    model = Phyloformer.from_checkpoint(args.weights, device=args.device)
+    model.eval()
+    load_s = time.perf_counter() - t0
+
     paths = glob(f"{in_dir}/*")
-    t_io = t_fwd = 0.0
-    n_done = 0
+    rank, world = 0, 1
+    if args.worker:
+        rank, world = (int(v) for v in args.worker.split("/"))
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])   # launched by torchrun
+    if world > 1:
+        for p in paths:
+            if not scheduler.has_fasta_ext(p):
+                raise ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{p}")
+        paths = scheduler.slice_paths(paths, rank, world)
 
-    def flush(group):
-        nonlocal t_fwd, t_io, n_done
-        if not group:
-            return
-        import numpy as np
-        t0 = time.perf_counter()
-        preds = model.engine.forward(np.stack([g[1] for g in group]))
-        t_fwd += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for (alnpath, _idx, ids), pred in zip(group, preds):
-            stem = Path(alnpath).stem
-            dm, phylip = vec_to_phylip(pred, ids)
-            with open(os.path.join(out_dir, f"{stem}.phy"), "w") as outfile:
-                outfile.write(phylip)
-            if args.trees:
-                from phyloformer_amd.nj import neighbor_joining
-                with open(os.path.join(out_dir, f"{stem}.nj.nwk"), "w") as outfile:
-                    outfile.write(neighbor_joining(dm.astype("float64"), ids))
-        t_io += time.perf_counter() - t0
-        n_done += len(group)
-        group.clear()
-
-    group = []
-    for alnpath in tqdm(paths):
-        if not has_fasta_ext(alnpath):
-            raise ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{alnpath}")
-        t0 = time.perf_counter()
-        idx, ids = load_alignment(alnpath)
-        t_io += time.perf_counter() - t0
-        if group and (group[0][1].shape != idx.shape or len(group) >= args.batch):
-            flush(group)
-        group.append((alnpath, idx, ids))
-    flush(group)
-
+    bar = tqdm(total=len(paths)) if (tqdm is not None and world == 1) else None
+    runner = scheduler.DirectoryRunner(model.engine, out_dir, trees=args.trees, batch=args.batch,
+                                       io_threads=args.io_threads, native_io=not args.python_io,
+                                       progress=bar.update if bar is not None else None)
+    try:
+        stats = runner.run(paths)
+    finally:
+        if bar is not None:
+            bar.close()
     if args.bench:
-        print(json.dumps({"alignments": n_done, "forward_s": round(t_fwd, 6), "io_s": round(t_io, 6),
-                          "alignments_per_s": round(n_done / t_fwd, 3) if t_fwd > 0 else None}),
-              file=sys.stderr)
+        rep = scheduler.summarize(stats, load_s)
+        rep["device"] = args.device
+        print(json.dumps(rep), file=sys.stderr)
     model.close()
     return 0
 

@@ -1,0 +1,201 @@
+"""Batched, shape-bucketed, I/O-overlapped inference over a directory of alignments.
+
+The reference loop (/root/reference/infer_alns.py:95-123) is strictly serial:
+parse one FASTA, run one forward, format and write one PHYLIP file.  On an
+MI355X the forward of a 60 x 500 alignment takes 2.3 ms — less than CPython
+needs for the parsing and formatting around it — so the CLI would be host-bound
+by a wide margin.  This module keeps the GPU fed:
+
+* loader threads parse FASTA files ahead of the GPU (native parser, GIL released);
+* alignments are *bucketed by shape* ``(N, L)``; a bucket is launched when it
+  holds ``batch`` alignments (or a token budget's worth), whatever order the
+  files arrived in, and all partial buckets are flushed at the end;
+* writer threads format and write the PHYLIP (and NJ) files of batch ``k`` while
+  the GPU runs batch ``k + 1``;
+* ``run_multi_device`` shards the *files* over several GPUs, one process per
+  GPU, no collective (alignment-level data parallelism, SURVEY.md §8e way 1).
+
+Every alignment is computed independently inside a launch; batching only changes
+how k_colstats splits the pair sum into groups, i.e. fp32 re-association noise
+(<= 2e-5 on the distances, tests/test_cli_gpu.py), far inside the 1e-4 parity bar.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import time
+from collections import OrderedDict, deque
+from concurrent.futures import Future, ThreadPoolExecutor
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# one launch should carry about this many (pair, site) tokens: 16 alignments of 60 x 500
+# (3.6 GB of residual stream), the size bench.py measures the headline number at
+TOKEN_BUDGET = 16 * 1770 * 500
+
+
+def auto_batch(n_seqs: int, n_sites: int, max_batch: int = 4096, token_budget: int = TOKEN_BUDGET) -> int:
+    """Alignments per launch for shape ``(N, L)``: fill the token budget, at least 1."""
+    tokens = max(1, n_seqs * (n_seqs - 1) // 2 * n_sites)
+    return int(min(max_batch, max(1, token_budget // tokens)))
+
+
+def has_fasta_ext(alnpath: str) -> bool:
+    """Checks if a path ends in .fa or .fasta (infer_alns.py:36-38)."""
+    return alnpath.lower().endswith(".fa") or alnpath.lower().endswith(".fasta")
+
+
+def slice_paths(paths: Sequence[str], rank: int, world: int) -> List[str]:
+    """Deterministic share of ``paths`` for worker ``rank`` of ``world``: files are sorted by
+    (size, name) and dealt round-robin, so every worker sees the same mix of shapes."""
+    if world <= 1:
+        return list(paths)
+
+    def key(p):
+        try:
+            return (os.path.getsize(p), p)
+        except OSError:
+            return (0, p)
+    return sorted(paths, key=key)[rank::world]
+
+
+class DirectoryRunner:
+    """Runs every alignment of a file list through ``engine`` and writes the outputs."""
+
+    def __init__(self, engine, out_dir: str, trees: bool = False, batch: int = 0,
+                 io_threads: int = 4, native_io: bool = True, progress=None):
+        self.engine = engine
+        self.out_dir = out_dir
+        self.trees = trees
+        self.batch = batch            # 0 = auto per shape
+        self.io_threads = max(1, io_threads)
+        self.native_io = native_io
+        self.progress = progress
+        self.stats = {"alignments": 0, "launches": 0, "forward_s": 0.0, "load_wait_s": 0.0,
+                      "write_wait_s": 0.0, "shapes": {}}
+
+    # -- stages -----------------------------------------------------------------------------
+    def _load(self, path: str):
+        if self.native_io:
+            from .hostio import load_alignment
+        else:
+            from .fasta import load_alignment
+        return load_alignment(path)
+
+    def _write(self, path: str, pred: np.ndarray, ids: List[str]):
+        stem = Path(path).stem
+        if self.native_io and not self.trees:
+            from .hostio import format_phylip
+            with open(os.path.join(self.out_dir, f"{stem}.phy"), "wb") as fh:
+                fh.write(format_phylip(pred, ids))
+            return
+        from .phylip import vec_to_phylip
+        dm, text = vec_to_phylip(pred, ids)
+        with open(os.path.join(self.out_dir, f"{stem}.phy"), "w") as fh:
+            fh.write(text)
+        if self.trees:
+            from .nj import neighbor_joining
+            with open(os.path.join(self.out_dir, f"{stem}.nj.nwk"), "w") as fh:
+                fh.write(neighbor_joining(dm.astype("float64"), ids))
+
+    def _launch(self, shape: Tuple[int, int], group: list, writers: ThreadPoolExecutor, pending: deque):
+        t0 = time.perf_counter()
+        preds = self.engine.forward(np.stack([g[1] for g in group]))
+        self.stats["forward_s"] += time.perf_counter() - t0
+        self.stats["launches"] += 1
+        self.stats["alignments"] += len(group)
+        key = f"{shape[0]}x{shape[1]}"
+        self.stats["shapes"][key] = self.stats["shapes"].get(key, 0) + len(group)
+        for (path, _idx, ids), pred in zip(group, preds):
+            pending.append(writers.submit(self._write, path, pred, ids))
+        if self.progress is not None:
+            self.progress(len(group))
+        # bound the write queue so results do not pile up in memory
+        t0 = time.perf_counter()
+        while len(pending) > 8 * self.io_threads + len(group):
+            pending.popleft().result()
+        self.stats["write_wait_s"] += time.perf_counter() - t0
+
+    # -- driver -----------------------------------------------------------------------------
+    def run(self, paths: Sequence[str]) -> dict:
+        for p in paths:
+            if not has_fasta_ext(p):
+                raise ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{p}")
+        t_start = time.perf_counter()
+        buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
+        pending: deque = deque()
+        lookahead = max(64, 4 * (self.batch or 64))
+        with ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-load") as loaders, \
+                ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-write") as writers:
+            inflight: "deque[Tuple[str, Future]]" = deque()
+            it = iter(paths)
+            exhausted = False
+            while True:
+                while not exhausted and len(inflight) < lookahead:
+                    try:
+                        p = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        break
+                    inflight.append((p, loaders.submit(self._load, p)))
+                if not inflight:
+                    break
+                path, fut = inflight.popleft()
+                t0 = time.perf_counter()
+                idx, ids = fut.result()          # parser exceptions surface here, as in the reference
+                self.stats["load_wait_s"] += time.perf_counter() - t0
+                shape = (int(idx.shape[0]), int(idx.shape[1]))
+                group = buckets.setdefault(shape, [])
+                group.append((path, idx, ids))
+                if len(group) >= (self.batch or auto_batch(*shape)):
+                    self._launch(shape, group, writers, pending)
+                    buckets[shape] = []
+            for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):
+                if group:
+                    self._launch(shape, group, writers, pending)
+            t0 = time.perf_counter()
+            while pending:
+                pending.popleft().result()
+            self.stats["write_wait_s"] += time.perf_counter() - t0
+        self.stats["wall_s"] = time.perf_counter() - t_start
+        return self.stats
+
+
+def summarize(stats: dict, load_s: float = 0.0) -> dict:
+    n, wall = stats["alignments"], stats.get("wall_s", 0.0)
+    return {"alignments": n, "launches": stats["launches"], "shapes": stats["shapes"],
+            "model_load_s": round(load_s, 4), "wall_s": round(wall, 6),
+            "forward_s": round(stats["forward_s"], 6),
+            "load_wait_s": round(stats["load_wait_s"], 6), "write_wait_s": round(stats["write_wait_s"], 6),
+            "alignments_per_s": round(n / wall, 3) if wall > 0 else None,
+            "alignments_per_s_forward_only": round(n / stats["forward_s"], 3) if stats["forward_s"] > 0 else None}
+
+
+def run_multi_device(script: str, argv: List[str], devices: Sequence[int]) -> Tuple[int, List[dict]]:
+    """One child process per GPU, each on its own share of the files (``--worker r/W``).
+    Children are started before any of them touches a GPU; the parent never does."""
+    procs = []
+    for r, d in enumerate(devices):
+        cmd = [sys.executable, script, *argv, "--device", str(d), "--worker", f"{r}/{len(devices)}", "--bench"]
+        procs.append(subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True))
+    rc, reports = 0, []
+    for p in procs:
+        _out, err = p.communicate()
+        rc = rc or p.returncode
+        rep = None
+        for line in (err or "").splitlines():
+            if line.startswith("{") and '"alignments"' in line:
+                try:
+                    rep = json.loads(line)
+                    continue
+                except ValueError:
+                    pass
+            if line.strip():
+                print(line, file=sys.stderr)
+        if rep is not None:
+            reports.append(rep)
+    return rc, reports

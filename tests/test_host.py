@@ -151,3 +151,73 @@ def test_neighbor_joining_recovers_additive_tree():
     assert nwk.endswith(";\n") and all(t in nwk for t in ids)
     lens = sorted(float(x) for x in re.findall(r":([0-9.eE+-]+)", nwk))
     assert lens == [1.0, 2.0, 2.0, 3.0, 4.0]
+
+
+# ---- native file-format helpers (csrc/pf_hostio.cpp) vs the Python mirrors of the reference ----------
+
+def _random_fasta(rng, n, l, wrap=None, crlf=False, pad_ids=False, blank_lines=False):
+    from phyloformer_amd.fasta import ALPHABET
+    out = []
+    for i in range(n):
+        seq = bytes(ALPHABET[c] for c in rng.integers(0, 22, l))
+        name = b"seq_%d" % i + (b"   " if pad_ids else b"")
+        out.append(b">" + name)
+        if wrap:
+            out += [seq[k:k + wrap] for k in range(0, l, wrap)]
+        else:
+            out.append(seq)
+        if blank_lines:
+            out.append(b"  \t ")
+    eol = b"\r\n" if crlf else b"\n"
+    return eol.join(out) + (eol if n % 2 else b"")
+
+
+def test_native_fasta_matches_python_parser(repo):
+    MSA_DIR = os.path.join(repo, "data/testdata/msas")
+    from phyloformer_amd import fasta, hostio
+    rng = np.random.default_rng(5)
+    for n, l, kw in [(2, 1, {}), (5, 33, dict(wrap=10)), (20, 250, dict(pad_ids=True)),
+                     (7, 64, dict(crlf=True, wrap=60)), (3, 17, dict(blank_lines=True)), (60, 500, {})]:
+        data = _random_fasta(rng, n, l, **kw)
+        a, ids_a = fasta.parse_fasta(data)
+        b, ids_b = hostio.parse_fasta(data)
+        assert ids_a == ids_b
+        assert a.shape == b.shape == (n, l) and a.dtype == b.dtype == np.uint8
+        assert np.array_equal(a, b)
+    # the reference's test alignments
+    for name in sorted(os.listdir(MSA_DIR))[:4]:
+        a, ids_a = fasta.load_alignment(os.path.join(MSA_DIR, name))
+        b, ids_b = hostio.load_alignment(os.path.join(MSA_DIR, name))
+        assert ids_a == ids_b and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("data,exc", [
+    (b">a\nARND\n>b\nARNB\n", KeyError),          # byte outside the alphabet (data.py:26)
+    (b">a\nARND\n>b\narnd\n", KeyError),          # lower case is not in the alphabet either
+    (b">a\nARND\n>b\nARN\n", ValueError),         # ragged
+    (b"ARND\n>a\nARND\n", IndexError),            # residues before the first header
+    (b"\n\n", ValueError),                        # nothing
+])
+def test_native_fasta_errors_match_python_parser(data, exc):
+    from phyloformer_amd import fasta, hostio
+    with pytest.raises(exc) as e1:
+        fasta.parse_fasta(data)
+    with pytest.raises(exc) as e2:
+        hostio.parse_fasta(data)
+    if exc is KeyError:
+        assert e1.value.args == e2.value.args
+
+
+def test_native_phylip_is_byte_identical_to_python_writer():
+    from phyloformer_amd import hostio
+    from phyloformer_amd.phylip import vec_to_phylip
+    rng = np.random.default_rng(11)
+    for n in (2, 3, 20, 61):
+        p = n * (n - 1) // 2
+        preds = (rng.random(p) * rng.choice([1e-6, 1.0, 30.0], p)).astype(np.float32)
+        preds[0] = 0.0
+        ids = [f"t{i}_é" if i % 7 == 0 else f"taxon{i}" for i in range(n)]
+        _dm, text = vec_to_phylip(preds, ids)
+        assert hostio.format_phylip(preds, ids) == text.encode("utf8")
+    with pytest.raises(ValueError):
+        hostio.format_phylip(np.zeros(4, np.float32), ["a", "b", "c"])

@@ -1,0 +1,100 @@
+"""CPU tests of the CLI scheduler (phyloformer_amd/scheduler.py) with a stand-in engine:
+shape bucketing, batch sizes, output files, error propagation, file sharding across workers."""
+import os
+
+import numpy as np
+import pytest
+
+from phyloformer_amd import fasta, scheduler
+from phyloformer_amd.phylip import vec_to_phylip
+
+
+class FakeEngine:
+    """forward(uint8 [B, N, L]) -> float32 [B, P]: a cheap deterministic function of each alignment."""
+
+    def __init__(self):
+        self.calls = []
+
+    def forward(self, idx):
+        idx = np.asarray(idx)
+        assert idx.ndim == 3 and idx.dtype == np.uint8
+        self.calls.append(idx.shape)
+        B, N, L = idx.shape
+        i, j = np.triu_indices(N, 1)
+        return (idx[:, i, :] != idx[:, j, :]).mean(axis=2).astype(np.float32)
+
+
+def _write_fasta(path, idx, prefix="s"):
+    with open(path, "wb") as fh:
+        for k, row in enumerate(idx):
+            fh.write(b">%s%d\n" % (prefix.encode(), k) + bytes(fasta.ALPHABET[c] for c in row) + b"\n")
+
+
+def _make_dir(tmp_path, shapes, seed=0):
+    rng = np.random.default_rng(seed)
+    d = tmp_path / "in"
+    d.mkdir()
+    truth = {}
+    for k, (n, l) in enumerate(shapes):
+        idx = rng.integers(0, 22, (n, l)).astype(np.uint8)
+        _write_fasta(d / f"aln{k:03d}.fa", idx)
+        truth[f"aln{k:03d}"] = idx
+    return d, truth
+
+
+@pytest.mark.parametrize("native_io", [True, False])
+@pytest.mark.parametrize("batch", [0, 1, 3])
+def test_directory_runner_buckets_by_shape_and_writes_everything(tmp_path, batch, native_io):
+    shapes = [(4, 30), (6, 20), (4, 30), (5, 11), (6, 20), (4, 30), (4, 30), (6, 20), (4, 31)]
+    d, truth = _make_dir(tmp_path, shapes)
+    out = tmp_path / "out"
+    out.mkdir()
+    eng = FakeEngine()
+    paths = sorted(str(p) for p in d.iterdir())
+    stats = scheduler.DirectoryRunner(eng, str(out), batch=batch, io_threads=3, native_io=native_io).run(paths)
+    assert stats["alignments"] == len(shapes)
+    assert stats["shapes"] == {"4x30": 4, "6x20": 3, "5x11": 1, "4x31": 1}
+    assert all(len({s[1:]}) == 1 for s in eng.calls)                      # one shape per launch
+    if batch == 1:
+        assert len(eng.calls) == len(shapes)
+    elif batch == 3:
+        assert sorted(s[0] for s in eng.calls) == [1, 1, 1, 3, 3]         # 4x30: 3+1, 6x20: 3, singles
+    else:
+        assert len(eng.calls) == 4                                        # auto: one launch per shape
+    ref = FakeEngine()
+    for stem, idx in truth.items():
+        ids = [f"s{k}" for k in range(idx.shape[0])]
+        _dm, text = vec_to_phylip(ref.forward(idx[None])[0], ids)
+        assert (out / f"{stem}.phy").read_text() == text
+
+
+def test_directory_runner_trees_and_errors(tmp_path):
+    d, _truth = _make_dir(tmp_path, [(5, 12), (5, 12)])
+    out = tmp_path / "out"
+    out.mkdir()
+    paths = sorted(str(p) for p in d.iterdir())
+    scheduler.DirectoryRunner(FakeEngine(), str(out), trees=True).run(paths)
+    nwk = (out / "aln000.nj.nwk").read_text()
+    assert nwk.endswith(";\n") and nwk.count(",") == 4
+    # a non-FASTA entry aborts with the reference's message (infer_alns.py:100-103)
+    (d / "notes.txt").write_text("x")
+    with pytest.raises(ValueError, match="Input files must be fasta files"):
+        scheduler.DirectoryRunner(FakeEngine(), str(out)).run(sorted(str(p) for p in d.iterdir()))
+    (d / "notes.txt").unlink()
+    # parser errors surface with the reference's exception types (data.py:26)
+    (d / "bad.fa").write_bytes(b">a\nARNDB\n>b\nARNDC\n")
+    with pytest.raises(KeyError):
+        scheduler.DirectoryRunner(FakeEngine(), str(out)).run(sorted(str(p) for p in d.iterdir()))
+
+
+def test_auto_batch_and_slicing(tmp_path):
+    assert scheduler.auto_batch(60, 500) == 16
+    assert scheduler.auto_batch(200, 500) == 1
+    assert scheduler.auto_batch(20, 200) == 372
+    assert scheduler.auto_batch(2, 1, max_batch=100) == 100
+    d, _ = _make_dir(tmp_path, [(3, 5 + (k % 4)) for k in range(11)])
+    paths = [str(p) for p in d.iterdir()]
+    parts = [scheduler.slice_paths(paths, r, 3) for r in range(3)]
+    assert sorted(sum(parts, [])) == sorted(paths)
+    assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    assert scheduler.slice_paths(paths, 0, 1) == paths

@@ -1,0 +1,34 @@
+"""End-to-end CLI throughput: write K synthetic FASTA files, run infer_alns.py on the directory.
+    python tools/cli_bench.py [--n 256] [--seqs 60] [--sites 500] [--extra "--batch 1 --python-io"]"""
+import argparse, json, os, shutil, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from phyloformer_amd.fasta import ALPHABET
+from phyloformer_amd.msa_sim import simulate_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=256)
+ap.add_argument("--seqs", type=int, default=60)
+ap.add_argument("--sites", type=int, default=500)
+ap.add_argument("--extra", default="")
+a = ap.parse_args()
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tmp = tempfile.mkdtemp(prefix="pfcli_")
+ind, outd = os.path.join(tmp, "in"), os.path.join(tmp, "out")
+os.makedirs(ind)
+base = simulate_batch(8, a.seqs, a.sites, seed=3)
+lut = np.frombuffer(ALPHABET, dtype=np.uint8)
+for k in range(a.n):
+    idx = np.roll(base[k % 8], k // 8, axis=1)
+    with open(os.path.join(ind, f"aln{k:05d}.fa"), "wb") as fh:
+        for i, row in enumerate(idx):
+            fh.write(b">taxon_%d\n" % i + lut[row].tobytes() + b"\n")
+t0 = time.perf_counter()
+r = subprocess.run([sys.executable, os.path.join(repo, "infer_alns.py"), os.path.join(repo, "models/pf.ckpt"),
+                    ind, "-o", outd, "--bench", *a.extra.split()], capture_output=True, text=True)
+wall = time.perf_counter() - t0
+rep = [l for l in r.stderr.splitlines() if l.startswith("{")]
+print(json.dumps({"files": a.n, "shape": [a.seqs, a.sites], "extra": a.extra, "process_wall_s": round(wall, 3),
+                  "returncode": r.returncode, "report": json.loads(rep[-1]) if rep else r.stderr[-500:]}))
+assert len(os.listdir(outd)) == a.n
+shutil.rmtree(tmp)
