@@ -61,11 +61,11 @@ def test_cli_bucketed_batches_equal_serial_order(repo, tmp_path):
     assert r.returncode == 0, r.stderr
     rep = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
     assert rep["alignments"] == 20 and rep["launches"] == 4 and len(rep["shapes"]) == 4
-    r = _run(repo, [os.path.join(repo, "models/pf.ckpt"), ind, "-o", str(b), "--batch", "1", "--python-io"])
+    r = _run(repo, [os.path.join(repo, "models/pf.ckpt"), ind, "-o", str(b), "--batch", "1", "--python-io", "-t"])
     assert r.returncode == 0, r.stderr
     gold = np.load(os.path.join(repo, "tests/golden/e2e_testdata.npz"))
     names = sorted(os.listdir(a))
-    assert names == sorted(os.listdir(b)) and len(names) == 20
+    assert names == sorted(n for n in os.listdir(b) if n.endswith(".phy")) and len(names) == 20
     for name in names:
         ids_a, dm_a = _read_phy(a / name)
         ids_b, dm_b = _read_phy(b / name)
@@ -76,3 +76,20 @@ def test_cli_bucketed_batches_equal_serial_order(repo, tmp_path):
         n = len(ids_a)
         ref = gold["pf/" + name[:-4]]
         assert np.abs(dm_a[np.triu_indices(n, 1)] - ref).max() <= 1e-4
+
+    # end-to-end tree check: NJ trees from the GPU distances have the topology of
+    # NJ trees from the reference's distances, and sit as close to the true trees (tests/test_treecmp.py)
+    from phyloformer_amd import treecmp
+    from phyloformer_amd.nj import neighbor_joining
+    from phyloformer_amd.phylip import vec_to_matrix
+    rf_vs_ref, nrf_vs_true = 0, []
+    for name in names:
+        stem = name[:-4]
+        ids, _dm = _read_phy(b / name)
+        mine = treecmp.parse_newick(open(b / f"{stem}.nj.nwk").read())
+        ref = treecmp.parse_newick(neighbor_joining(vec_to_matrix(gold["pf/" + stem], len(ids)).astype(np.float64), ids))
+        true = treecmp.parse_newick(open(os.path.join(repo, "data/testdata/trees", stem + ".nwk")).read())
+        rf_vs_ref += treecmp.robinson_foulds(mine, ref)[0]
+        nrf_vs_true.append(treecmp.robinson_foulds(mine, true)[1])
+    assert rf_vs_ref <= 2                     # at most one near-tie resolved differently over 20 trees
+    assert abs(np.mean(nrf_vs_true) - 0.1857) <= 0.005

@@ -1,0 +1,94 @@
+"""Tree comparison (phyloformer_amd/treecmp.py) and the end-to-end tree check on the reference's
+own distances."""
+import os
+
+import numpy as np
+import pytest
+
+from phyloformer_amd import fasta, treecmp
+from phyloformer_amd.nj import neighbor_joining
+from phyloformer_amd.phylip import vec_to_matrix
+
+FASTME = "/root/reference/bin/bin_linux/fastme"
+
+
+def test_newick_parser_and_splits():
+    t = treecmp.parse_newick("((A:1,B:2)x:0.5,(C:1,'D d':1):0.25,E:3)[comment];")
+    assert treecmp.leaf_names(t) == ["A", "B", "C", "D d", "E"]
+    sp = treecmp.splits(t)
+    internal = {k: v for k, v in sp.items() if 1 < len(k) < 4}
+    # {A,B} | rest is stored as the side without the smallest leaf "A"
+    assert internal == {frozenset(["C", "D d", "E"]): 0.5, frozenset(["C", "D d"]): 0.25}
+    for bad in ("(A,B)", "((A,B);", "(A,B));", "(A,'B);"):
+        with pytest.raises(ValueError):
+            treecmp.parse_newick(bad)
+
+
+def test_rf_known_values_and_rooting_invariance():
+    a = treecmp.parse_newick("(((A,B),C),(D,E),F);")
+    same_rooted_elsewhere = treecmp.parse_newick("((A,B),(C,((D,E),F)));")
+    assert treecmp.robinson_foulds(a, same_rooted_elsewhere) == (0, 0.0)
+    b = treecmp.parse_newick("(((A,C),B),(D,E),F);")          # one split differs: AB vs AC
+    assert treecmp.robinson_foulds(a, b) == (2, 2 / 6)
+    star = treecmp.parse_newick("(A,B,C,D,E,F);")
+    assert treecmp.robinson_foulds(a, star) == (3, 1.0)
+    with pytest.raises(ValueError):
+        treecmp.robinson_foulds(a, treecmp.parse_newick("(A,B,(C,D));"))
+
+
+def test_branch_score_and_root_edge_merging():
+    a = treecmp.parse_newick("((A:1,B:1):1,(C:1,D:1):1);")     # bifurcating root: one unrooted edge of 2
+    b = treecmp.parse_newick("((A:1,B:1):2,C:1,D:1);")
+    assert treecmp.branch_score(a, b) == pytest.approx(0.0)
+    c = treecmp.parse_newick("((A:1,B:1):2,C:1,D:4);")
+    assert treecmp.branch_score(a, c) == pytest.approx(3.0)
+    d = treecmp.parse_newick("((A:1,C:1):2,B:1,D:1);")         # different topology: both internal edges count
+    assert treecmp.branch_score(a, d) == pytest.approx(np.sqrt(8.0))
+
+
+def test_nj_recovers_true_trees_from_their_patristic_distances(repo):
+    tdir = os.path.join(repo, "data/testdata/trees")
+    for name in sorted(os.listdir(tdir))[::4]:
+        true = treecmp.parse_newick(open(os.path.join(tdir, name)).read())
+        names, dm = treecmp.patristic(true)
+        est = treecmp.parse_newick(neighbor_joining(dm, names))
+        assert treecmp.robinson_foulds(true, est)[0] == 0
+        assert treecmp.branch_score(true, est) <= 1e-9
+
+
+def _tree_check(repo, golden, to_tree):
+    gold = golden("e2e_testdata.npz")
+    rows = []
+    for name in sorted(os.listdir(os.path.join(repo, "data/testdata/msas"))):
+        stem = name[:-3]
+        _idx, ids = fasta.load_alignment(os.path.join(repo, "data/testdata/msas", name))
+        dm = vec_to_matrix(gold[f"pf/{stem}"], len(ids)).astype(np.float64)
+        true = treecmp.parse_newick(open(os.path.join(repo, "data/testdata/trees", stem + ".nwk")).read())
+        est = treecmp.parse_newick(to_tree(dm, ids))
+        rows.append(treecmp.robinson_foulds(true, est) + (treecmp.branch_score(true, est),))
+    return np.mean(np.array(rows, dtype=np.float64), axis=0)
+
+
+def test_end_to_end_tree_check_on_reference_distances(repo, golden):
+    """pf.ckpt distances of the reference (goldens) -> NJ -> vs the true trees of data/testdata/trees.
+    The values are the yard-stick for the GPU run (tests/test_cli_gpu.py)."""
+    rf, nrf, kf = _tree_check(repo, golden, neighbor_joining)
+    assert rf == pytest.approx(11.4) and nrf == pytest.approx(0.1857, abs=5e-4) and kf == pytest.approx(0.3964, abs=5e-4)
+
+
+@pytest.mark.skipif(not os.path.exists(FASTME), reason="FastME binary of the reference checkout not present")
+def test_end_to_end_tree_check_with_fastme(repo, golden, tmp_path):
+    """README.md:83-96 of the reference: FastME --nni --spr on the predicted matrices.  The README's
+    'average KF 0.333' comes from `phylocompare`, which is missing from the checkout, so that figure is
+    unpinned; this pins the build's own comparison on the same pipeline instead."""
+    import subprocess
+    from phyloformer_amd.hostio import format_phylip
+
+    def fastme(dm, ids):
+        n = len(ids)
+        (tmp_path / "m.phy").write_bytes(format_phylip(dm[np.triu_indices(n, 1)], ids))
+        subprocess.run([FASTME, "-i", str(tmp_path / "m.phy"), "-o", str(tmp_path / "t.nwk"), "--nni", "--spr"],
+                       check=True, capture_output=True)
+        return (tmp_path / "t.nwk").read_text()
+    rf, nrf, kf = _tree_check(repo, golden, fastme)
+    assert rf == pytest.approx(11.2) and nrf == pytest.approx(0.1837, abs=5e-4) and kf == pytest.approx(0.3935, abs=5e-4)
