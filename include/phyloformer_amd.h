@@ -139,7 +139,8 @@ int pf_memcpy_h2d(pf_handle_t* h, void* dst, const void* src, size_t bytes);
 int pf_memcpy_d2h(pf_handle_t* h, void* dst, const void* src, size_t bytes);
 
 /* Per-kernel HIP-event timing ("profile" = 1).  Names: "embed", "rowfin",
- * "colstats", "colfin", "main", "allreduce".  Totals accumulate until reset. */
+ * "colstats", "colfin", "main", "allreduce", "mha_qkv", "mha_attn", "mha_out".  Totals accumulate
+ * until reset. */
 int pf_profile_reset(pf_handle_t* h);
 int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double* total_ms);
 

@@ -171,8 +171,9 @@ struct BlockDev {
 };
 
 struct ProfSlot { int kid; hipEvent_t a, b; };
-const char* const KNAMES[] = {"embed", "rowfin", "colstats", "colfin", "main", "allreduce"};
-enum { K_EMBED = 0, K_ROWFIN, K_COLSTATS, K_COLFIN, K_MAIN, K_ALLREDUCE, K_COUNT };
+const char* const KNAMES[] = {"embed", "rowfin", "colstats", "colfin", "main", "allreduce",
+                              "mha_qkv", "mha_attn", "mha_out"};
+enum { K_EMBED = 0, K_ROWFIN, K_COLSTATS, K_COLFIN, K_MAIN, K_ALLREDUCE, K_MHA_QKV, K_MHA_ATTN, K_MHA_OUT, K_COUNT };
 
 }  // namespace
 
@@ -1112,13 +1113,22 @@ int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, i
     const int cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
     const int lin_tiles = rows * ntiles;
     const int g1 = std::max(1, std::min((lin_tiles + 3) / 4, cus * 3));
-    hipLaunchKernelGGL(k_mha_qkv, dim3(g1), dim3(256), 0, h->stream, a);
+    {
+        ProfScope ps(h, K_MHA_QKV);
+        hipLaunchKernelGGL(k_mha_qkv, dim3(g1), dim3(256), 0, h->stream, a);
+    }
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(k_mha_attn, dim3(rows * MHA_H * ((ntiles + 3) / 4)), dim3(256), 0, h->stream, a);
+    {
+        ProfScope ps(h, K_MHA_ATTN);
+        hipLaunchKernelGGL(k_mha_attn, dim3(rows * MHA_H * ((ntiles + 3) / 4)), dim3(256), 0, h->stream, a);
+    }
     HIPCHK(h, hipGetLastError());
     const int64_t out_tiles = ((int64_t)rows * C + 31) / 32;
     const int g3 = (int)std::max<int64_t>(1, std::min<int64_t>((out_tiles + 3) / 4, cus * 8));
-    hipLaunchKernelGGL(k_mha_out, dim3(g3), dim3(256), 0, h->stream, a);
+    {
+        ProfScope ps(h, K_MHA_OUT);
+        hipLaunchKernelGGL(k_mha_out, dim3(g3), dim3(256), 0, h->stream, a);
+    }
     HIPCHK(h, hipGetLastError());
     return PF_OK;
 }
