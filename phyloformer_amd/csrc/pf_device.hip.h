@@ -173,7 +173,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // FFN hidden activation for two accumulator values at once, fused with the bf16 hi/lo split.
 // The FFN weights are pre-scaled on the host so that the accumulator holds a*h with
 // a^2 = log2(e)/2 (the variable the activation polynomial below is fitted in) and W2 carries 1/a;
-// the function returns a*gelu(h) as packed bf16 pairs:  hi = bf16(g), lo = bf16(g - hi).
+// the function returns 2*a*gelu(h) as packed bf16 pairs (W2 carries 1/(2a)):  hi = bf16(g), lo = bf16(g - hi).
 // Scalar VOP3 forms with free |x| / -x modifiers; built with -fno-slp-vectorize so that hipcc does
 // not re-pack them into v_pk_* (see gelu_scaled).
 constexpr float GELU_ALPHA = 0.84932180028801904272f;   // sqrt(log2(e) / 2)
@@ -184,17 +184,16 @@ __device__ __forceinline__ float gelu_scaled(float x) {
     // = ~30 VALU cycles, against 45 for the Abramowitz-Stegun form (rcp + exp + 10 ops) it replaces.
     // Plain (non-packed) fp32 ops only: on gfx950 v_pk_fma_f32 / v_pk_mul_f32 do not overlap with
     // another wave's MFMAs (MFMA || v_pk_fma = sum of both, MFMA || v_fma = max) - tools/valu_bench.hip.
+    // Returned value is 2*a*gelu(h) = x + |x| (1 - 2 Q): the factor 2 (folded into W2 on the host, exact)
+    // turns max(x, 0) - |x| Q into one subtraction and one FMA; v_max_f32 costs 4.4 cycles per wave
+    // instruction on gfx950 against 2.5 for add / mul / fma (tools/overlap3_bench.hip).
     const float u = fabsf(x);
     float p = fmaf(-0.00107098569f, u, 0.0136151873f);
     p = fmaf(p, u, -0.084594565f);
     p = fmaf(p, u, -0.637684925f);
     p = fmaf(p, u, -1.35494915f);
-    p = fmaf(p, u, -1.00003762f);
-    // fmaxf() would first canonicalise x (a second v_max x, x); the asm names p as an input only to
-    // stay behind the compiler-visible first reader of the MFMA result x (hazard padding)
-    float m;
-    asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x), "v"(p));
-    return fmaf(-u, __builtin_amdgcn_exp2f(p), m);
+    p = fmaf(p, u, -0.00003762f);                       // log2(2 Q): constant term of log2 Q plus one
+    return fmaf(u, 1.f - __builtin_amdgcn_exp2f(p), x);
 }
 // (g0, g1) -> packed bf16 pairs hi = bf16(g), lo = bf16(g - hi).  The residual g - hi comes from
 // v_dot2c_f32_bf16 (g += hi.lo * -1 + hi.hi * 0): one 4.5-cycle op instead of unpack (4.2) + subtract
@@ -210,8 +209,15 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
 #define PF_DOT2C_PRE ""
 #define PF_DOT2C_POST "\n\ts_nop 2"
 #endif
+#ifdef PF_SPLIT_NODOT
+    // same residual through plain VALU (shift / mask / subtract): two more instructions per pair, but
+    // unlike v_dot2c (matrix-side datapath) they can issue in the shadow of another wave's MFMA
+    r0 = g0 - __builtin_bit_cast(float, hb << 16);
+    r1 = g1 - __builtin_bit_cast(float, hb & 0xffff0000u);
+#else
     asm volatile(PF_DOT2C_PRE "v_dot2c_f32_bf16 %0, %2, %4\n\tv_dot2c_f32_bf16 %1, %3, %4" PF_DOT2C_POST
                  : "+v"(r0), "+v"(r1) : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(hb));
+#endif
     const bf16x2 l2 = {(__bf16)r0, (__bf16)r1};
     hi_out = hb;
     lo_out = __builtin_bit_cast(unsigned, l2);

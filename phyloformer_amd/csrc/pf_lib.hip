@@ -366,7 +366,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         for (auto& v : w1f) v = (float)((double)v * alpha);
         for (auto& v : b1f) v = (float)((double)v * alpha);
         std::vector<float> w2s((size_t)E * FF);
-        for (size_t i = 0; i < w2s.size(); ++i) w2s[i] = (float)((double)ffn[k].w2[i] / alpha);
+        for (size_t i = 0; i < w2s.size(); ++i) w2s[i] = (float)((double)ffn[k].w2[i] / alpha * 0.5);   // gelu_scaled returns 2*a*gelu
         std::vector<uint16_t> img((size_t)FRAG_END * 8);
         pack_frags(w1f.data(), FF, E, FF, img.data() + (size_t)FRAG_W1 * 8);
         pack_frags(w2s.data(), E, FF, E, img.data() + (size_t)FRAG_W2 * 8);
