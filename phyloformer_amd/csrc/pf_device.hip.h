@@ -667,6 +667,86 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 #undef PF_TICK
 }
 
+// ---- embedding + pair expansion + row statistics of block 0 by table lookup ----------------------
+// x0[p = (i, j)][l] = T[a_i[l]] + T[a_j[l]] (model.py:173-175) takes only 22 x 22 values per site, so
+// everything block 0's row attention needs from a token - q' (4), k' (4) and k' (x) v (64), i.e. its
+// 72-float contribution to the row statistics - is a function of the residue pair and is tabulated on
+// the host in double precision (pf_lib.hip::build_pair_table).  The kernel sums table rows over the
+// sites of a pair (LDS-resident table, 139 KB), writes q' per token and materialises x0 for the two
+// consumers of block 0.  No LayerNorm, no MFMA: it replaces k_main<MODE_FIRST> (1.41 -> ~0.6 ms per
+// batch of 16 alignments, now bound by the 3.6 GB write of x0).
+constexpr int PAIRTAB_ROWS = 22 * 22, PAIRTAB_W = 72;
+constexpr int EMBED_THREADS = 512;
+constexpr int EMBED_LDS_BYTES = (PAIRTAB_ROWS * PAIRTAB_W + 22 * 64) * 4;
+struct EmbedArgs {
+    const uint8_t* idx;      // [B][N][Lloc]
+    const int16_t* pair_i;   // [P]
+    const int16_t* pair_j;
+    const float* ptab;       // [484][72]  S_kv contribution (64) | q' (4) | k' (4)
+    const float* table;      // [22][64]
+    float* x;                // [B*P][Lloc][64]
+    float* qrow;             // [B*P][Lloc][4]
+    float* srow;             // [B*P][72]
+    int B, N, P, Lloc;
+};
+
+__global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];
+    float* tab = esm;
+    float* emb = esm + PAIRTAB_ROWS * PAIRTAB_W;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.ptab);
+        f32x4* dst = reinterpret_cast<f32x4*>(tab);
+        for (int i = threadIdx.x; i < PAIRTAB_ROWS * PAIRTAB_W / 4; i += EMBED_THREADS) dst[i] = src[i];
+        const f32x4* s2 = reinterpret_cast<const f32x4*>(a.table);
+        f32x4* d2 = reinterpret_cast<f32x4*>(emb);
+        for (int i = threadIdx.x; i < 22 * 64 / 4; i += EMBED_THREADS) d2[i] = s2[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sg = lane >> 4, cl = lane & 15;     // 4 sites per wave instruction, 4 channels per lane
+    const int ntasks = a.B * a.P;
+    for (int task = blockIdx.x * (EMBED_THREADS / 64) + wave; task < ntasks; task += gridDim.x * (EMBED_THREADS / 64)) {
+        const int b = task / a.P, p = task - b * a.P;
+        const uint8_t* ri = a.idx + ((size_t)b * a.N + a.pair_i[p]) * a.Lloc;
+        const uint8_t* rj = a.idx + ((size_t)b * a.N + a.pair_j[p]) * a.Lloc;
+        const size_t row0 = (size_t)task * a.Lloc;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acce = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int l0 = 0; l0 < a.Lloc; l0 += 4) {
+            const int l = l0 + sg;
+            const bool valid = l < a.Lloc;
+            const int lc = valid ? l : a.Lloc - 1;
+            const int ra = ri[lc], rb = rj[lc];
+            const float* tr = tab + (ra * 22 + rb) * PAIRTAB_W;
+            const f32x4 s = *reinterpret_cast<const f32x4*>(tr + 4 * cl);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(tr + 64 + 4 * (cl & 1));   // even lanes q', odd k'
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(emb + ra * 64 + 4 * cl);
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(emb + rb * 64 + 4 * cl);
+            if (valid) {
+                acc += s;
+                acce += e;
+                const size_t tok = row0 + l;
+                *reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * cl) = xa + xb;
+                if (cl == 0) *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = e;
+            }
+        }
+        // sum the four site sub-groups (lanes 16 and 32 apart)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += __shfl_xor(acc[i], 16);
+            acc[i] += __shfl_xor(acc[i], 32);
+            acce[i] += __shfl_xor(acce[i], 16);
+            acce[i] += __shfl_xor(acce[i], 32);
+        }
+        if (sg == 0) {
+            float* sr = a.srow + (size_t)task * SROW;
+            *reinterpret_cast<f32x4*>(sr + 4 * cl) = acc;
+            if (cl < 2) *reinterpret_cast<f32x4*>(sr + 64 + 4 * cl) = acce;
+        }
+    }
+}
+
 // ---- row finalisation: srow -> mrow ------------------------------------------------------
 struct RowFinArgs {
     const float* srow;   // [B*P][72]

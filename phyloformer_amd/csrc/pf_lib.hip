@@ -194,6 +194,8 @@ struct pf_handle {
     int64_t ws_limit_bytes = (int64_t)24 << 30;  // per-chunk workspace budget
     // weights
     float* table = nullptr;       // [22][64]
+    float* pair_table = nullptr;  // [484][72] block-0 row-attention contributions per residue pair (k_embed)
+    bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
     float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
     std::vector<BlockDev> blk;
@@ -283,6 +285,42 @@ void fold(const float* W, const float* bias, const float* g, const float* beta, 
     }
 }
 
+// Row-attention quantities of block 0 for every residue pair (a, b), in double precision:
+//   x0 = T[a] + T[b] (fp32 sum, as the device forms it), xn = LayerNorm(x0) g + beta,
+//   q' = elu(Wq xn + bq) + 1, k' likewise, v = Wv' LN(x0) without any bias (the folded bias is added in
+//   k_rowfin);  row = [ k'[c >> 4] v[c] (64) | q' (4) | k' (4) ]  -> k_embed sums rows over the sites.
+void build_pair_table(const float* table, const AttnHost& r, std::vector<float>& out) {
+    out.assign((size_t)PAIRTAB_ROWS * PAIRTAB_W, 0.f);
+    auto elu1 = [](double z) { return z > 0 ? z + 1.0 : std::exp(z); };
+    for (int a = 0; a < NA; ++a)
+        for (int b = 0; b < NA; ++b) {
+            double x[E], xn[E], mean = 0, var = 0;
+            for (int c = 0; c < E; ++c) { x[c] = (double)(table[a * E + c] + table[b * E + c]); mean += x[c]; }
+            mean /= E;
+            for (int c = 0; c < E; ++c) var += (x[c] - mean) * (x[c] - mean);
+            const double rstd = 1.0 / std::sqrt(var / E + (double)LN_EPS);
+            for (int c = 0; c < E; ++c) xn[c] = (x[c] - mean) * rstd;
+            double q[NH], k[NH];
+            for (int hh = 0; hh < NH; ++hh) {
+                double zq = r.bq[hh], zk = r.bk[hh];
+                for (int c = 0; c < E; ++c) {
+                    const double y = xn[c] * (double)r.g[c] + (double)r.b[c];
+                    zq += (double)r.wq[hh * E + c] * y;
+                    zk += (double)r.wk[hh * E + c] * y;
+                }
+                q[hh] = elu1(zq);
+                k[hh] = elu1(zk);
+            }
+            float* row = out.data() + (size_t)(a * NA + b) * PAIRTAB_W;
+            for (int co = 0; co < E; ++co) {
+                double v = 0;
+                for (int c = 0; c < E; ++c) v += (double)r.wv[co * E + c] * (double)r.g[c] * xn[c];
+                row[co] = (float)(k[co >> 4] * v);
+            }
+            for (int hh = 0; hh < NH; ++hh) { row[64 + hh] = (float)q[hh]; row[68 + hh] = (float)k[hh]; }
+        }
+}
+
 int prepare_weights(pf_handle* h, const pf_weights_t* w) {
     Blob bl{w->blob};
     const float* emb_w = bl.take((size_t)E * NA);
@@ -315,6 +353,11 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         return fail(h, PF_EINVAL, "weight blob has %llu floats, expected %llu",
                     (unsigned long long)w->blob_len, (unsigned long long)(bl.p - w->blob));
 
+    {
+        std::vector<float> ptab;
+        build_pair_table(table.data(), rows[0], ptab);
+        if ((rc = upload(h, ptab, &h->pair_table))) return rc;
+    }
     std::vector<std::vector<float>> row_bqk(nb);
     std::vector<std::vector<uint16_t>> row_tail(nb);
     for (int k = 0; k < nb; ++k) {
@@ -539,11 +582,28 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
 
 // embedding + pair expansion + row statistics of block 0
 int phase_first(pf_handle* h, const ShardRun& r) {
-    MainArgs m = main_args(h, r);
-    m.wimg = reinterpret_cast<const bf16x8*>(h->first_img); m.consts = h->first_consts;
-    m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[0].wv_lo);
-    int rc = launch_main<MODE_FIRST>(h, m, K_EMBED);
-    if (rc) return rc;
+    int rc;
+    if (h->embed_mfma) {
+        MainArgs m = main_args(h, r);
+        m.wimg = reinterpret_cast<const bf16x8*>(h->first_img); m.consts = h->first_consts;
+        m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[0].wv_lo);
+        rc = launch_main<MODE_FIRST>(h, m, K_EMBED);
+        if (rc) return rc;
+    } else {
+        static bool attr_set[16] = {false};
+        if (!attr_set[h->device & 15]) {
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, EMBED_LDS_BYTES));
+            attr_set[h->device & 15] = true;
+        }
+        EmbedArgs e{r.d_idx, h->pair_i, h->pair_j, h->pair_table, h->table, r.w.x, r.w.qrow, r.w.srow,
+                    r.B, r.N, r.P, r.Lloc};
+        const int ntasks = r.B * r.P, wpb = EMBED_THREADS / 64;
+        const int grid = std::max(1, std::min(h->prop.multiProcessorCount, (ntasks + wpb - 1) / wpb));
+        ProfScope ps(h, K_EMBED);
+        hipLaunchKernelGGL(k_embed, dim3(grid), dim3(EMBED_THREADS), EMBED_LDS_BYTES, h->stream, e);
+        HIPCHK(h, hipGetLastError());
+    }
     if (h->debug_keep) return save_tap(h, "x0", r.w.x, (size_t)r.B * r.P * r.Lloc * 64);
     return PF_OK;
 }
@@ -791,6 +851,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     if (k == "max_seqs") h->max_seqs = value;
     else if (k == "profile") { drain_profile(h); h->profile = value != 0; h->profile_main_only = value == 2; }
     else if (k == "debug_keep") h->debug_keep = value != 0;
+    else if (k == "embed_mfma") h->embed_mfma = value != 0;
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
     else if (k == "phase_prof") {

@@ -168,3 +168,32 @@ def test_full_range_shard_equals_forward(engines, golden):
     e = engines("pf")
     a = g["c2_idx"][:1]
     assert np.array_equal(e.forward_sharded(a, 0, 200, 200), e.forward(a))
+
+
+def test_table_embedding_equals_mfma_embedding(engines, golden):
+    """Block 0's row statistics come from a host-built residue-pair table (k_embed); the MFMA
+    formulation it replaced (k_main<MODE_FIRST>, option "embed_mfma") must give the same taps and
+    the same distances."""
+    e = engines("pf_indel")
+    rng = np.random.default_rng(12)
+    idx = rng.integers(0, 22, (2, 9, 75)).astype(np.uint8)          # all 22 symbols incl. X and gap
+    taps = {}
+    for mode in (0, 1):
+        e.set_option("embed_mfma", mode)
+        e.set_option("debug_keep", 1)
+        d = e.forward(idx)
+        taps[mode] = (d, e.debug_read("x0"), e.debug_read("srow0"))
+        e.set_option("debug_keep", 0)
+    e.set_option("embed_mfma", 0)
+    assert np.array_equal(taps[0][1], taps[1][1])                    # x0: the same fp32 sums
+    s0, s1 = taps[0][2].reshape(-1, 72), taps[1][2].reshape(-1, 72)
+    assert np.abs(s0 - s1).max() <= 2e-5 * np.abs(s1).max()
+    # distances: random residues are an ill-conditioned input (see test_tiny_taps...), so compare on the
+    # scale of the output there and absolutely on a simulated alignment
+    assert np.abs(taps[0][0] - taps[1][0]).max() <= 5e-5 * max(1.0, np.abs(taps[1][0]).max())
+    g = golden("configs.npz")
+    e.set_option("embed_mfma", 1)
+    d1 = e.forward(g["c2_idx"])
+    e.set_option("embed_mfma", 0)
+    d0 = e.forward(g["c2_idx"])
+    assert np.abs(d0 - d1).max() <= 2e-5
