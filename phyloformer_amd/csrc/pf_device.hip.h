@@ -814,121 +814,161 @@ struct ColStatsArgs {
 };
 constexpr int CPART = 4 * 64 + 8;
 
-// Block = (alignment b, chunk of 4 sites, pair group g); 4 waves stride over the
-// group's pairs.  Lanes: site = lane >> 4, channels 4*(lane & 15) .. +3, so one
-// wave-load is 1 KB contiguous.  Applies the row attention on the fly (it is not
-// materialised in HBM), then LayerNorm -> q', k' -> Z~ += k' x~.
+// Block = (alignment b, chunk of 32 sites, pair group g); wave w owns sites 8w .. 8w+7 of the chunk and
+// all four waves walk the group's pairs together, so the block reads 8 KB of contiguous x per pair and
+// shares the per-pair row-attention matrix.  Lanes: site = lane >> 3, channels 8*(lane & 7) .. +7 (two
+// 16-byte loads per lane).  Applies the row attention on the fly (it is not materialised in HBM), then
+// LayerNorm -> q', k' -> Z~ += k' x~.  Eight lanes per token: three steps per cross-lane reduction and,
+// after the transposing butterfly, exactly one projection per lane - 24 VALU instructions per token.
 __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
-    __shared__ float red[4][64][17];
+    // two staging buffers of 16 pair matrices (5 x 64 floats each)
+    __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ts = lane >> 4, cl = lane & 15;
+    const int ts = lane >> 3, cl = lane & 7;
     int bid = blockIdx.x;
     const int g = bid % a.G; bid /= a.G;
     const int chunk = bid % a.nchunks;
     const int b = bid / a.nchunks;
-    const int l = chunk * 4 + ts;
+    const int l = chunk * 32 + wave * 8 + ts;
     const bool lvalid = l < a.Lloc;
     const int lcl = lvalid ? l : a.Lloc - 1;
     const int per = (a.P + a.G - 1) / a.G;
     const int p0 = g * per, p1 = min(a.P, p0 + per);
 
-    float w[8][4];
+    float w[8][8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(a.wqk + o * 64 + 4 * cl);
+    for (int o = 0; o < 8; ++o)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[o][i] = u[i];
-    }
-    // After the transposing reduction below lane cl holds projection j = cl >> 1
-    // (j < 4: q'[j], else k'[j - 4]); lanes cl and cl ^ 1 hold the same value.
-    const int j = cl >> 1;
-    const float bj = a.bqk[j];
-    const bool up3 = (cl & 8) != 0, up2 = (cl & 4) != 0, up1 = (cl & 2) != 0;
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(a.wqk + o * 64 + 8 * cl + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[o][4 * q + i] = u[i];
+        }
+    // after the transposing reduction lane cl holds projection cl (0-3: q', 4-7: k')
+    const float bj = a.bqk[cl];
+    const bool up2 = (cl & 4) != 0, up1 = (cl & 2) != 0, up0 = (cl & 1) != 0;
     const float vmask = lvalid ? 1.f : 0.f;
-    float z[4][4], s_acc = 0.f;
+    float z[4][8], s_acc = 0.f;
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[hh][i] = 0.f;
+        for (int i = 0; i < 8; ++i) z[hh][i] = 0.f;
 
-    for (int p = p0 + wave; p < p1; p += 4) {
+    // the next pair's token row and q' are requested one iteration ahead (two ahead measured no better)
+    f32x4 nx0, nx1, nqr;
+    auto fetch = [&](int p) {
+        const size_t tk = ((size_t)b * a.P + min(p, a.P - 1)) * a.Lloc + lcl;
+        nx0 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
+        nx1 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
+        nqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
+    };
+    // The per-pair row-attention matrices are staged through LDS 16 pairs at a time (double-buffered):
+    // read straight from L2, every 8-lane group of every wave would fetch them again - 10 KB of L1
+    // traffic per 8 tokens against 2 KB of x.
+    f32x4 stg[5];
+    auto stage_load = [&](int pt) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.mrow + ((size_t)b * a.P + pt) * MROW);
+        const int n4 = min(16, p1 - pt) * (MROW / 4);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) stg[k] = src[min((int)threadIdx.x + 256 * k, n4 - 1)];
+    };
+    auto stage_store = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(mst + (size_t)buf * 16 * MROW);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[threadIdx.x + 256 * k] = stg[k];
+    };
+    if (p0 < p1) { stage_load(p0); stage_store(0); fetch(p0); }
+    __syncthreads();
+    int buf = 0;
+    for (int pt = p0; pt < p1; pt += 16, buf ^= 1) {
+      const bool more = pt + 16 < p1;
+      if (more) stage_load(pt + 16);                       // lands during this tile's compute
+      const float* mt = mst + (size_t)buf * 16 * MROW;
+      const int pe = min(pt + 16, p1);
+      for (int p = pt; p < pe; ++p) {
         const size_t pr = (size_t)b * a.P + p;
         const size_t tok = pr * a.Lloc + lcl;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + tok * 64 + 4 * cl);
-        const f32x4 qr = *reinterpret_cast<const f32x4*>(a.qrow + tok * 4);
-        const float* m = a.mrow + pr * MROW + 4 * cl;
-        f32x4 y = *reinterpret_cast<const f32x4*>(m + 4 * 64);
+        const f32x4 xv0 = nx0, xv1 = nx1, qr = nqr;
+        fetch(p + 1);
+        const float* m = mt + (p - pt) * MROW + 8 * cl;
+        f32x4 y0 = *reinterpret_cast<const f32x4*>(m + 4 * 64), y1 = *reinterpret_cast<const f32x4*>(m + 4 * 64 + 4);
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
-            const f32x4 mv = *reinterpret_cast<const f32x4*>(m + hh * 64);
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + hh * 64);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = fmaf(qr[hh], mv[i], y[i]);
+            for (int i = 0; i < 4; ++i) { y0[i] = fmaf(qr[hh], m0[i], y0[i]); y1[i] = fmaf(qr[hh], m1[i], y1[i]); }
         }
-        float xr[4];
         // x' = x + row attention of this block (bias row included)
+        float d[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[i] = xv[i] + y[i];
-        const float mean = row16_sum((xr[0] + xr[1]) + (xr[2] + xr[3])) * (1.f / 64.f);
-        float d[4], v = 0.f;
+        for (int i = 0; i < 4; ++i) { d[i] = xv0[i] + y0[i]; d[4 + i] = xv1[i] + y1[i]; }
+        float sm = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+        sm += dpp_f<0x141>(sm);     // row_half_mirror: lane i <-> 7 - i
+        sm += dpp_f<0x1B>(sm);      // quad reverse
+        sm += dpp_f<0xB1>(sm);      // xor 1
+        const float mean = sm * (1.f / 64.f);
+        float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { d[i] = xr[i] - mean; v = fmaf(d[i], d[i], v); }
-        const float rstd = __builtin_amdgcn_rsqf(row16_sum(v) * (1.f / 64.f) + LN_EPS);
+        for (int i = 0; i < 8; ++i) { d[i] -= mean; v = fmaf(d[i], d[i], v); }
+        v += dpp_f<0x141>(v);
+        v += dpp_f<0x1B>(v);
+        v += dpp_f<0xB1>(v);
+        const float rstd = __builtin_amdgcn_rsqf(v * (1.f / 64.f) + LN_EPS);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] *= rstd;
-        // eight 64-long dot products: 4 channels per lane, then a transposing butterfly over the
-        // 16 lanes of the token (row_mirror, row_half_mirror, quad reverse, xor 1): 22 VALU
-        // instead of 32 DPP adds + 8 activations per lane
+        for (int i = 0; i < 8; ++i) d[i] *= rstd;
+        // eight 64-long dot products: 8 channels per lane, then a transposing butterfly over the
+        // 8 lanes of the token (half mirror, quad reverse, xor 1)
         float pv[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) pv[o] = fmaf(w[o][3], d[3], fmaf(w[o][2], d[2], fmaf(w[o][1], d[1], w[o][0] * d[0])));
+        for (int o = 0; o < 8; ++o) {
+            float acc = w[o][0] * d[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) acc = fmaf(w[o][i], d[i], acc);
+            pv[o] = acc;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float send = up3 ? pv[i] : pv[i + 4], keep = up3 ? pv[i + 4] : pv[i];
-            pv[i] = keep + dpp_f<0x140>(send);
+            const float send = up2 ? pv[i] : pv[i + 4], keep = up2 ? pv[i + 4] : pv[i];
+            pv[i] = keep + dpp_f<0x141>(send);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float send = up2 ? pv[i] : pv[i + 2], keep = up2 ? pv[i + 2] : pv[i];
-            pv[i] = keep + dpp_f<0x141>(send);
+            const float send = up1 ? pv[i] : pv[i + 2], keep = up1 ? pv[i + 2] : pv[i];
+            pv[i] = keep + dpp_f<0x1B>(send);
         }
         {
-            const float send = up1 ? pv[0] : pv[1], keep = up1 ? pv[1] : pv[0];
-            pv[0] = keep + dpp_f<0x1B>(send);
+            const float send = up0 ? pv[0] : pv[1], keep = up0 ? pv[1] : pv[0];
+            pv[0] = keep + dpp_f<0xB1>(send);
         }
-        const float act = elu1_fast(pv[0] + dpp_f<0xB1>(pv[0]) + bj) * vmask;   // q'[j] or k'[j-4]
+        const float act = elu1_fast(pv[0] + bj) * vmask;   // q'[cl] or k'[cl - 4]
         s_acc += act;
-        if (lvalid && cl < 8 && (cl & 1) == 0) a.qcol[tok * 4 + j] = act;
-        // k'[hh] sits in lanes 8 + 2 hh (and +1) of this token's 16-lane row
-        const float k0 = swz<((8 + 0) << 5) | 0x10>(act), k1 = swz<((8 + 2) << 5) | 0x10>(act),
-                    k2 = swz<((8 + 4) << 5) | 0x10>(act), k3 = swz<((8 + 6) << 5) | 0x10>(act);
+        if (lvalid && cl < 4) a.qcol[tok * 4 + cl] = act;
+        // k'[hh] sits in lane 4 + hh of this token's 8-lane group
+        const float k0 = swz<(4 << 5) | 0x18>(act), k1 = swz<(5 << 5) | 0x18>(act),
+                    k2 = swz<(6 << 5) | 0x18>(act), k3 = swz<(7 << 5) | 0x18>(act);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             z[0][i] = fmaf(k0, d[i], z[0][i]);
             z[1][i] = fmaf(k1, d[i], z[1][i]);
             z[2][i] = fmaf(k2, d[i], z[2][i]);
             z[3][i] = fmaf(k3, d[i], z[3][i]);
         }
+      }
+      if (more) stage_store(buf ^ 1);
+      __syncthreads();
     }
-    // cross-wave reduction through LDS, then one partial per (b, g, site)
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][lane][hh * 4 + i] = z[hh][i];
-    red[wave][lane][16] = s_acc;
-    __syncthreads();
-    if (wave == 0 && lvalid) {
+    // every wave owns its sites: one partial per (b, g, site), no cross-wave reduction
+    if (lvalid) {
         float* out = a.part + (((size_t)b * a.G + g) * a.Lloc + l) * CPART;
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            f32x4 u;
+        for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                u[i] = red[0][lane][hh * 4 + i] + red[1][lane][hh * 4 + i] +
-                       red[2][lane][hh * 4 + i] + red[3][lane][hh * 4 + i];
-            *reinterpret_cast<f32x4*>(out + hh * 64 + 4 * cl) = u;
-        }
-        if ((cl & 1) == 0)   // S_q[0..3] | S_k[0..3]
-            out[256 + j] = red[0][lane][16] + red[1][lane][16] + red[2][lane][16] + red[3][lane][16];
+            for (int q = 0; q < 2; ++q) {
+                f32x4 u = {z[hh][4 * q], z[hh][4 * q + 1], z[hh][4 * q + 2], z[hh][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(out + hh * 64 + 8 * cl + 4 * q) = u;
+            }
+        out[256 + cl] = s_acc;      // S_q[0..3] | S_k[0..3]
     }
 }
 

@@ -458,7 +458,7 @@ struct Workspace {
 };
 
 int colstats_groups(int B, int P, int Lloc) {
-    const int chunks = (Lloc + 3) / 4;
+    const int chunks = (Lloc + 31) / 32;
     int G = (1024 + B * chunks - 1) / (B * chunks);
     G = std::min(G, std::max(1, P / 32));
     return std::max(1, std::min(G, 32));
@@ -622,7 +622,7 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, const float* srow) {
         HIPCHK(h, hipGetLastError());
     }
     {
-        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 3) / 4};
+        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32};
         ProfScope ps(h, K_COLSTATS);
         hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
         HIPCHK(h, hipGetLastError());
