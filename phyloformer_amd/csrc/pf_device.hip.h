@@ -222,25 +222,15 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
     hi_out = hb;
     lo_out = __builtin_bit_cast(unsigned, l2);
 }
-__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {
+__device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {   // tools/
     split_pair(gelu_scaled(x0), gelu_scaled(x1), hi_out, lo_out);
 }
-// eight accumulator values acc[base .. base+7] -> one B-operand fragment pair
-__device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8& hi, bf16x8& lo) {
-    u32x4 h, l;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        unsigned a, b;
-        gelu_split_pair(acc[base + 2 * k], acc[base + 2 * k + 1], a, b);
-        h[k] = a;
-        l[k] = b;
-    }
-    hi = __builtin_bit_cast(bf16x8, h);
-    lo = __builtin_bit_cast(bf16x8, l);
-}
-
-// split 8 floats into bf16 hi + bf16 lo (x ~= hi + lo to 2^-17 relative)
+// split 8 floats into bf16 hi + bf16 lo fragments (x ~= hi + lo to 2^-17 relative).  The eight
+// v_dot2c residuals are issued back to back in one asm block: each then sits >= 2 instructions ahead of
+// the first reader of its result, and a single s_nop covers the last one - instead of one pad per
+// pair as in split_pair (the pads alone were ~3 % of k_main's issue slots).
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#ifdef PF_SPLIT_NODOT
     u32x4 h, l;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -251,6 +241,37 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
     hi = __builtin_bit_cast(bf16x8, h);
     lo = __builtin_bit_cast(bf16x8, l);
+#else
+    u32x4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bf16x2 h2 = {(__bf16)v[2 * k], (__bf16)v[2 * k + 1]};
+        h[k] = __builtin_bit_cast(unsigned, h2);
+    }
+    float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7];
+    asm volatile(
+        "v_dot2c_f32_bf16 %0, %8, %10\n\tv_dot2c_f32_bf16 %1, %9, %10\n\t"
+        "v_dot2c_f32_bf16 %2, %8, %11\n\tv_dot2c_f32_bf16 %3, %9, %11\n\t"
+        "v_dot2c_f32_bf16 %4, %8, %12\n\tv_dot2c_f32_bf16 %5, %9, %12\n\t"
+        "v_dot2c_f32_bf16 %6, %8, %13\n\tv_dot2c_f32_bf16 %7, %9, %13\n\ts_nop 1"
+        : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+        : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    const bf16x2 l0 = {(__bf16)r0, (__bf16)r1}, l1 = {(__bf16)r2, (__bf16)r3}, l2 = {(__bf16)r4, (__bf16)r5},
+                 l3 = {(__bf16)r6, (__bf16)r7};
+    l[0] = __builtin_bit_cast(unsigned, l0);
+    l[1] = __builtin_bit_cast(unsigned, l1);
+    l[2] = __builtin_bit_cast(unsigned, l2);
+    l[3] = __builtin_bit_cast(unsigned, l3);
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+#endif
+}
+// eight accumulator values acc[base .. base+7] -> GELU -> one B-operand fragment pair
+__device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8& hi, bf16x8& lo) {
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = gelu_scaled(acc[base + k]);
+    split8(g, hi, lo);
 }
 
 #define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
