@@ -284,6 +284,16 @@ __device__ __forceinline__ void mfma3(f32x16& acc, const bf16x8& a_hi, const bf1
     acc = PF_MFMA(a_hi, b_hi, acc);
 }
 
+// first product of a chain: C is the inline constant 0 of the MFMA encoding, so the accumulator needs no
+// sixteen v_mov to be cleared
+__device__ __forceinline__ void mfma3_zero(f32x16& acc, const bf16x8& a_hi, const bf16x8& a_lo,
+                                           const bf16x8& b_hi, const bf16x8& b_lo) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc = PF_MFMA(a_lo, b_hi, z);
+    acc = PF_MFMA(a_hi, b_lo, acc);
+    acc = PF_MFMA(a_hi, b_hi, acc);
+}
+
 // LayerNorm without affine over the 64 channels of a token held by lanes (t,0) and (t,1)
 __device__ __forceinline__ void ln_pair(const float (&x)[32], float (&xn)[32]) {
     float s = 0.f;
@@ -468,8 +478,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         const bf16x8* mf = a.mfrag + (size_t)task * 128 + t;
 #pragma unroll
                         for (int To = 0; To < 2; ++To) {
-                            bf16x8 m_hi = zero_frag(), m_lo = zero_frag();
-                            if (h == 0) { m_hi = mf[To * 64]; m_lo = mf[To * 64 + 32]; }
+                            // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do,
+                            // so they read their partner's fragment instead of branching around the load
+                            const bf16x8 m_hi = mf[To * 64], m_lo = mf[To * 64 + 32];
                             mfma3(ya[To], m_hi, m_lo, qb_hi, qb_lo);
                         }
                     }
@@ -583,12 +594,6 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 }
                 if (a.ablate & 32) continue;   // perf experiment: copy-only
                 f32x16 va[3];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    va[0][r] = 0.f;
-                    va[1][r] = 0.f;
-                    va[2][r] = (r < 4) ? lc[CONST_BQK + 4 * h + r] : 0.f;  // rows 0-3 q, 4-7 k
-                }
                 {
                     float xn[32];
                     ln_pair(x, xn);
@@ -599,21 +604,22 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     // LayerNorm, the split and these 12 MFMAs to arrive from L2
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        bf16x8 q_hi = zero_frag(), q_lo = zero_frag();
-                        if (t < 8) {
-                            q_hi = qkp[(s * 2) * 16];
-                            q_lo = qkp[(s * 2 + 1) * 16];
-                        }
-                        mfma3(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
+                        // output rows >= 8 are never read: lanes t >= 8 reuse rows t & 7 (finite) unmasked
+                        const bf16x8 q_hi = qkp[(s * 2) * 16], q_lo = qkp[(s * 2 + 1) * 16];
+                        if (s == 0) mfma3_zero(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
+                        else mfma3(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
                     }
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int T = 0; T < 2; ++T) {
                             const bf16x8 f_hi = wvp[(T * 4 + s) * 64];
-                            mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
+                            if (s == 0) mfma3_zero(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
+                            else mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
                         }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) va[2][r] += lc[CONST_BQK + 4 * h + r];   // rows 0-3 q, 4-7 k
                 float qk[4], ot[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) qk[i] = elu1_fast(va[2][i]);
