@@ -421,7 +421,14 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         // The next tile's residual rows and q' are requested when the FFN of the current tile starts
         // (the residual lives in the GEMM2 accumulators from then on, see below) and land during
         // its ~6 us of matrix work, so a tile never starts by waiting on HBM.
-        f32x4 px[8], pqr, pqc;
+        // the pair's row-mix fragments are loaded once per row, not once per tile
+        bf16x8 mfr[4];
+        if (MODE != MODE_FIRST) {
+            const bf16x8* mf = a.mfrag + (size_t)task * 128 + t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mfr[q] = mf[q * 32];
+        }
+        f32x4 px[8], pctx[8], pqr, pqc;
         auto prefetch = [&](int tl) {
             const int ll = min(tl * 32 + t, a.Lloc - 1);
             const size_t tk = row0 + ll;
@@ -430,6 +437,11 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             for (int g = 0; g < 8; ++g) px[g] = xp[2 * g];
             pqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
             pqc = *reinterpret_cast<const f32x4*>(a.qcol + tk * 4);
+            if (MODE != MODE_FIRST) {
+                const f32x4* cp = reinterpret_cast<const f32x4*>(a.ctx + ((size_t)b * a.Lloc + ll) * 64 + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) pctx[g] = cp[2 * g];
+            }
         };
         if (MODE != MODE_FIRST) prefetch(0);
 
@@ -475,24 +487,18 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         v[5] = v[6] = v[7] = 0.f;
                         bf16x8 qb_hi, qb_lo;
                         split8(v, qb_hi, qb_lo);
-                        const bf16x8* mf = a.mfrag + (size_t)task * 128 + t;
+                        // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do, so
+                        // they hold their partner's fragment instead of a masked load
 #pragma unroll
-                        for (int To = 0; To < 2; ++To) {
-                            // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do,
-                            // so they read their partner's fragment instead of branching around the load
-                            const bf16x8 m_hi = mf[To * 64], m_lo = mf[To * 64 + 32];
-                            mfma3(ya[To], m_hi, m_lo, qb_hi, qb_lo);
-                        }
+                        for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo);
                     }
                     // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
                     {
                         const f32x4 qc = pqc;
-                        const f32x4* cp = reinterpret_cast<const f32x4*>(
-                            a.ctx + ((size_t)b * a.Lloc + lc_) * 64 + 4 * h);
                         float o[32];
 #pragma unroll
                         for (int g = 0; g < 8; ++g) {
-                            const f32x4 u = cp[2 * g];
+                            const f32x4 u = pctx[g];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) o[4 * g + i] = u[i] * qc[g >> 1];
                         }
