@@ -12,7 +12,7 @@ alignment ``OUTDIR/<stem>.phy`` receives the PHYLIP distance matrix
 
 Additive flags (not in the reference): ``--device`` / ``--devices 0,1,...`` (one
 process per GPU, files sharded), ``--batch`` (same-shape alignments per launch;
-default: fill a token budget per shape), ``--io-threads``, ``--python-io``,
+default: fill a token budget per shape), ``--io-threads``, ``--gpu-streams``, ``--python-io``,
 ``--bench`` (print a JSON timing line).  Scheduling lives in
 ``phyloformer_amd/scheduler.py``: files are bucketed by shape, parsed ahead of the
 GPU and written behind it.  Unlike the reference, a non-FASTA entry aborts the run
@@ -49,6 +49,9 @@ def build_parser():
                         help="same-shape alignments per launch; 0 (default) = fill a token budget per shape, "
                              "1 = one alignment per launch as in the reference")
     parser.add_argument("--io-threads", type=int, default=4, help="FASTA loader / PHYLIP writer threads")
+    parser.add_argument("--gpu-streams", type=int, default=2,
+                        help="engines (HIP streams, one host thread each) per GPU; 2 hides the host-side gaps "
+                             "of a synchronous forward, 1 = one launch sequence at a time")
     parser.add_argument("--python-io", action="store_true",
                         help="use the pure-Python FASTA parser and PHYLIP writer instead of the native ones")
     parser.add_argument("--worker", default=None, help=argparse.SUPPRESS)   # "r/W": share r of W of the files
@@ -111,7 +114,11 @@ def main(argv=None):
         paths = scheduler.slice_paths(paths, rank, world)
 
     bar = tqdm(total=len(paths)) if (tqdm is not None and world == 1) else None
-    runner = scheduler.DirectoryRunner(model.engine, out_dir, trees=args.trees, batch=args.batch,
+    engines = [model.engine]
+    if args.batch != 1:
+        from phyloformer_amd.engine import Engine
+        engines += [Engine(model.weights, device=args.device) for _ in range(max(1, args.gpu_streams) - 1)]
+    runner = scheduler.DirectoryRunner(engines, out_dir, trees=args.trees, batch=args.batch,
                                        io_threads=args.io_threads, native_io=not args.python_io,
                                        progress=bar.update if bar is not None else None)
     try:
@@ -123,6 +130,8 @@ def main(argv=None):
         rep = scheduler.summarize(stats, load_s)
         rep["device"] = args.device
         print(json.dumps(rep), file=sys.stderr)
+    for e in engines[1:]:
+        e.close()
     model.close()
     return 0
 

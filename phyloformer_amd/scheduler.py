@@ -12,6 +12,8 @@ by a wide margin.  This module keeps the GPU fed:
   files arrived in, and all partial buckets are flushed at the end;
 * writer threads format and write the PHYLIP (and NJ) files of batch ``k`` while
   the GPU runs batch ``k + 1``;
+* two engines on two host threads (``--gpu-streams``) keep the GPU busy across the
+  host-side gaps of the synchronous ``pf_forward``;
 * ``run_multi_device`` shards the *files* over several GPUs, one process per
   GPU, no collective (alignment-level data parallelism, SURVEY.md §8e way 1).
 
@@ -23,8 +25,10 @@ from __future__ import annotations
 
 import json
 import os
+import queue
 import subprocess
 import sys
+import threading
 import time
 from collections import OrderedDict, deque
 from concurrent.futures import Future, ThreadPoolExecutor
@@ -64,11 +68,15 @@ def slice_paths(paths: Sequence[str], rank: int, world: int) -> List[str]:
 
 
 class DirectoryRunner:
-    """Runs every alignment of a file list through ``engine`` and writes the outputs."""
+    """Runs every alignment of a file list through the engine(s) and writes the outputs.
+
+    ``engine`` may be one engine or a list: each engine gets its own host thread (one HIP stream each),
+    so the host-side gaps of one synchronous ``pf_forward`` (index copy, result copy, Python between
+    calls) are filled by the other's kernels — measured 486 -> 501 alignments/s at 60 x 500 with two."""
 
     def __init__(self, engine, out_dir: str, trees: bool = False, batch: int = 0,
                  io_threads: int = 4, native_io: bool = True, progress=None):
-        self.engine = engine
+        self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
         self.out_dir = out_dir
         self.trees = trees
         self.batch = batch            # 0 = auto per shape
@@ -76,7 +84,8 @@ class DirectoryRunner:
         self.native_io = native_io
         self.progress = progress
         self.stats = {"alignments": 0, "launches": 0, "forward_s": 0.0, "load_wait_s": 0.0,
-                      "write_wait_s": 0.0, "shapes": {}}
+                      "write_wait_s": 0.0, "shapes": {}, "gpu_streams": len(self.engines)}
+        self._lock = threading.Lock()
 
     # -- stages -----------------------------------------------------------------------------
     def _load(self, path: str):
@@ -102,23 +111,41 @@ class DirectoryRunner:
             with open(os.path.join(self.out_dir, f"{stem}.nj.nwk"), "w") as fh:
                 fh.write(neighbor_joining(dm.astype("float64"), ids))
 
-    def _launch(self, shape: Tuple[int, int], group: list, writers: ThreadPoolExecutor, pending: deque):
+    def _launch(self, engine, shape: Tuple[int, int], group: list, writers: ThreadPoolExecutor, pending: deque):
         t0 = time.perf_counter()
-        preds = self.engine.forward(np.stack([g[1] for g in group]))
-        self.stats["forward_s"] += time.perf_counter() - t0
-        self.stats["launches"] += 1
-        self.stats["alignments"] += len(group)
-        key = f"{shape[0]}x{shape[1]}"
-        self.stats["shapes"][key] = self.stats["shapes"].get(key, 0) + len(group)
-        for (path, _idx, ids), pred in zip(group, preds):
-            pending.append(writers.submit(self._write, path, pred, ids))
-        if self.progress is not None:
-            self.progress(len(group))
-        # bound the write queue so results do not pile up in memory
+        preds = engine.forward(np.stack([g[1] for g in group]))
+        dt = time.perf_counter() - t0
+        with self._lock:
+            self.stats["forward_s"] += dt
+            self.stats["launches"] += 1
+            self.stats["alignments"] += len(group)
+            key = f"{shape[0]}x{shape[1]}"
+            self.stats["shapes"][key] = self.stats["shapes"].get(key, 0) + len(group)
+            for (path, _idx, ids), pred in zip(group, preds):
+                pending.append(writers.submit(self._write, path, pred, ids))
+            if self.progress is not None:
+                self.progress(len(group))
+            drain = []
+            # bound the write queue so results do not pile up in memory
+            while len(pending) > 8 * self.io_threads + len(group):
+                drain.append(pending.popleft())
         t0 = time.perf_counter()
-        while len(pending) > 8 * self.io_threads + len(group):
-            pending.popleft().result()
-        self.stats["write_wait_s"] += time.perf_counter() - t0
+        for f in drain:
+            f.result()
+        with self._lock:
+            self.stats["write_wait_s"] += time.perf_counter() - t0
+
+    def _gpu_worker(self, engine, jobs: "queue.Queue", writers, pending, errors: list):
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            if errors:
+                continue                      # drain the queue after a failure
+            try:
+                self._launch(engine, job[0], job[1], writers, pending)
+            except BaseException as exc:      # noqa: BLE001 - re-raised in run()
+                errors.append(exc)
 
     # -- driver -----------------------------------------------------------------------------
     def run(self, paths: Sequence[str]) -> dict:
@@ -128,35 +155,49 @@ class DirectoryRunner:
         t_start = time.perf_counter()
         buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
         pending: deque = deque()
+        errors: list = []
         lookahead = max(64, 4 * (self.batch or 64))
+        jobs: "queue.Queue" = queue.Queue(maxsize=2 * len(self.engines))
         with ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-load") as loaders, \
                 ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-write") as writers:
-            inflight: "deque[Tuple[str, Future]]" = deque()
-            it = iter(paths)
-            exhausted = False
-            while True:
-                while not exhausted and len(inflight) < lookahead:
-                    try:
-                        p = next(it)
-                    except StopIteration:
-                        exhausted = True
+            workers = [threading.Thread(target=self._gpu_worker, args=(e, jobs, writers, pending, errors),
+                                        name=f"pf-gpu{k}", daemon=True) for k, e in enumerate(self.engines)]
+            for w in workers:
+                w.start()
+            try:
+                inflight: "deque[Tuple[str, Future]]" = deque()
+                it = iter(paths)
+                exhausted = False
+                while not errors:
+                    while not exhausted and len(inflight) < lookahead:
+                        try:
+                            p = next(it)
+                        except StopIteration:
+                            exhausted = True
+                            break
+                        inflight.append((p, loaders.submit(self._load, p)))
+                    if not inflight:
                         break
-                    inflight.append((p, loaders.submit(self._load, p)))
-                if not inflight:
-                    break
-                path, fut = inflight.popleft()
-                t0 = time.perf_counter()
-                idx, ids = fut.result()          # parser exceptions surface here, as in the reference
-                self.stats["load_wait_s"] += time.perf_counter() - t0
-                shape = (int(idx.shape[0]), int(idx.shape[1]))
-                group = buckets.setdefault(shape, [])
-                group.append((path, idx, ids))
-                if len(group) >= (self.batch or auto_batch(*shape)):
-                    self._launch(shape, group, writers, pending)
-                    buckets[shape] = []
-            for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):
-                if group:
-                    self._launch(shape, group, writers, pending)
+                    path, fut = inflight.popleft()
+                    t0 = time.perf_counter()
+                    idx, ids = fut.result()          # parser exceptions surface here, as in the reference
+                    self.stats["load_wait_s"] += time.perf_counter() - t0
+                    shape = (int(idx.shape[0]), int(idx.shape[1]))
+                    group = buckets.setdefault(shape, [])
+                    group.append((path, idx, ids))
+                    if len(group) >= (self.batch or auto_batch(*shape)):
+                        jobs.put((shape, group))
+                        buckets[shape] = []
+                for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):
+                    if group and not errors:
+                        jobs.put((shape, group))
+            finally:
+                for _ in workers:
+                    jobs.put(None)
+                for w in workers:
+                    w.join()
+            if errors:
+                raise errors[0]
             t0 = time.perf_counter()
             while pending:
                 pending.popleft().result()
@@ -169,10 +210,12 @@ def summarize(stats: dict, load_s: float = 0.0) -> dict:
     n, wall = stats["alignments"], stats.get("wall_s", 0.0)
     return {"alignments": n, "launches": stats["launches"], "shapes": stats["shapes"],
             "model_load_s": round(load_s, 4), "wall_s": round(wall, 6),
-            "forward_s": round(stats["forward_s"], 6),
+            "gpu_streams": stats.get("gpu_streams", 1),
+            "forward_s": round(stats["forward_s"], 6),      # summed over the streams' host threads
             "load_wait_s": round(stats["load_wait_s"], 6), "write_wait_s": round(stats["write_wait_s"], 6),
             "alignments_per_s": round(n / wall, 3) if wall > 0 else None,
-            "alignments_per_s_forward_only": round(n / stats["forward_s"], 3) if stats["forward_s"] > 0 else None}
+            "alignments_per_s_forward_only": round(n * stats.get("gpu_streams", 1) / stats["forward_s"], 3)
+            if stats["forward_s"] > 0 else None}
 
 
 def run_multi_device(script: str, argv: List[str], devices: Sequence[int]) -> Tuple[int, List[dict]]:

@@ -98,3 +98,25 @@ def test_auto_batch_and_slicing(tmp_path):
     assert sorted(sum(parts, [])) == sorted(paths)
     assert max(map(len, parts)) - min(map(len, parts)) <= 1
     assert scheduler.slice_paths(paths, 0, 1) == paths
+
+
+def test_two_gpu_worker_threads_and_worker_errors(tmp_path):
+    shapes = [(4, 30)] * 9 + [(6, 20)] * 5 + [(5, 11)]
+    d, truth = _make_dir(tmp_path, shapes)
+    out = tmp_path / "out"
+    out.mkdir()
+    engs = [FakeEngine(), FakeEngine()]
+    paths = sorted(str(p) for p in d.iterdir())
+    stats = scheduler.DirectoryRunner(engs, str(out), batch=2, io_threads=2).run(paths)
+    assert stats["alignments"] == len(shapes) and stats["launches"] == 5 + 3 + 1
+    assert len(engs[0].calls) + len(engs[1].calls) == 9
+    ref = FakeEngine()
+    for stem, idx in truth.items():
+        _dm, text = vec_to_phylip(ref.forward(idx[None])[0], [f"s{k}" for k in range(idx.shape[0])])
+        assert (out / f"{stem}.phy").read_text() == text
+
+    class Boom(FakeEngine):
+        def forward(self, idx):
+            raise RuntimeError("device lost")
+    with pytest.raises(RuntimeError, match="device lost"):
+        scheduler.DirectoryRunner([Boom(), Boom()], str(out), batch=2).run(paths)
