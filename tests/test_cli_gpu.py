@@ -97,3 +97,20 @@ def test_cli_bucketed_batches_equal_serial_order(repo, tmp_path):
     print("RF(mine, ref) summed over 20 trees:", rf_vs_ref, " mean nRF vs true:", np.mean(nrf_vs_true))
     assert rf_vs_ref <= 12
     assert abs(np.mean(nrf_vs_true) - 0.1857) <= 0.01
+
+
+def test_cli_file_sharding_over_worker_processes(repo, tmp_path):
+    """--devices: one worker process per listed device, each on its share of the files (here the same
+    GPU twice, which exercises the process fan-out, --worker slicing and report aggregation)."""
+    ind = os.path.join(repo, "data/testdata/msas")
+    out = tmp_path / "out"
+    r = _run(repo, [os.path.join(repo, "models/pf.ckpt"), ind, "-o", str(out), "--devices", "0,0", "--bench"])
+    assert r.returncode == 0, r.stderr
+    rep = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+    assert rep["alignments"] == 20 and len(rep["workers"]) == 2
+    assert sorted(w["alignments"] for w in rep["workers"]) == [10, 10]
+    assert len([n for n in os.listdir(out) if n.endswith(".phy")]) == 20
+    gold = np.load(os.path.join(repo, "tests/golden/e2e_testdata.npz"))
+    for name in sorted(os.listdir(out)):
+        ids, dm = _read_phy(out / name)
+        assert np.abs(dm[np.triu_indices(len(ids), 1)] - gold["pf/" + name[:-4]]).max() <= 1e-4
