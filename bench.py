@@ -78,7 +78,7 @@ def cpu_baseline(w, n_seqs, n_sites):
     from oracle import pf_oracle_torch
     from phyloformer_amd.msa_sim import simulate_batch
     # 32 threads: the fastest of 16/32/64/256 on the 2 x 64-core GPU host (9.9 s vs 59.6 s with all
-    # 256 hardware threads, where the OpenMP pool oversubscribes) - tools/cpu_threads.py
+    # 256 hardware threads, where the OpenMP pool oversubscribes) - tests/dev/cpu_threads.py
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     pf_oracle_torch.forward(w.tensors, simulate_batch(1, 20, 100, seed=9)[0])   # thread-pool warm-up

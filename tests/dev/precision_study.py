@@ -2,7 +2,7 @@
 operand of the big GEMMs (FFN 64->256->64, Wv', Wo) to a short format cost?  Used to decide between the
 3-pass split-bf16 MFMA scheme and cheaper 2-pass schemes.  Not part of the product path."""
 import sys, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import oracle.pf_oracle as O
 from phyloformer_amd import weights as Wt
 
