@@ -106,6 +106,7 @@ def main():
     from phyloformer_amd.weights import load_weights
     from phyloformer_amd import dist as pfdist
 
+    comm_note = None
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -114,13 +115,31 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     w = load_weights(args.ckpt)
-    eng = Engine(w, device=local_rank)
+    # PF_BENCH_DEVICE: test aid - put every rank on one device (a 1-GPU box can then exercise the N > 1
+    # launch path; RCCL refuses two ranks on one GPU, which also exercises the fallback below)
+    eng = Engine(w, device=int(os.environ.get("PF_BENCH_DEVICE", local_rank)))
     if args.force_dist and world == 1:
         eng.set_option("force_rccl", 1)
         uid = pfdist.broadcast_bytes(eng.unique_id(), 128, src=0)
         eng.comm_init(uid, 0, 1)
     elif world > 1 and args.shard == "sites":
-        pfdist.init_engine_comm(eng)
+        # every rank must agree on whether the RCCL communicator came up: if it did not (librccl missing,
+        # init error) on any rank, all of them fall back to sharding whole alignments (no collective) so
+        # the scaling run still measures something, and the line says so
+        import torch
+        ok, why = 1, ""
+        try:
+            pfdist.init_engine_comm(eng)
+        except Exception as exc:  # noqa: BLE001
+            ok, why = 0, f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rank == 0:
+                print(f"bench: RCCL communicator unavailable ({why or 'failed on another rank'}); "
+                      "falling back to --shard alignments", file=sys.stderr)
+            args.shard = "alignments"
+            comm_note = "site-sharding unavailable (RCCL init failed), alignments sharded instead"
 
     N, L = args.n_seqs, args.n_sites
     P = N * (N - 1) // 2
@@ -210,6 +229,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": None,
         }
+        if comm_note:
+            line["config"]["note"] = comm_note
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, N, L)
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)

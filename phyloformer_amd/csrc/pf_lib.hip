@@ -898,9 +898,9 @@ int pf_comm_unique_id(void* id_out) {
 int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t world_size) {
     if (!h || world_size < 1 || rank < 0 || rank >= world_size) return PF_EINVAL;
     if (h->comm) return fail(h, PF_ESTATE, "communicator already initialised");
-    h->rank = rank;
-    h->world = world_size;
-    if (world_size == 1 && !h->force_rccl) return PF_OK;
+    // rank / world are only recorded once the communicator exists: after a failed init the handle is
+    // still a working single-rank engine
+    if (world_size == 1 && !h->force_rccl) { h->rank = 0; h->world = 1; return PF_OK; }
     if (!unique_id) return fail(h, PF_EINVAL, "null unique id");
     std::string err;
     if (!load_rccl(err)) return fail(h, PF_ERCCL, "%s", err.c_str());
@@ -912,6 +912,8 @@ int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t wo
         h->comm = nullptr;
         return fail(h, PF_ERCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
     }
+    h->rank = rank;
+    h->world = world_size;
     return PF_OK;
 }
 
