@@ -221,3 +221,25 @@ def test_native_phylip_is_byte_identical_to_python_writer():
         assert hostio.format_phylip(preds, ids) == text.encode("utf8")
     with pytest.raises(ValueError):
         hostio.format_phylip(np.zeros(4, np.float32), ["a", "b", "c"])
+
+
+def test_native_fasta_parser_agrees_with_python_on_arbitrary_bytes():
+    """Property test: for any byte string over a FASTA-like alphabet the native parser returns what the
+    Python mirror of data.py:11-31 returns, or raises the same exception class."""
+    from hypothesis import given, settings, strategies as st
+    from phyloformer_amd import hostio
+
+    alphabet = st.sampled_from([b">", b"\n", b"\r\n", b" ", b"\t", b"A", b"R", b"-", b"X", b"V", b"a", b"B", b"seq", b"\x0b"])
+
+    @settings(max_examples=400, deadline=None)
+    @given(st.lists(alphabet, max_size=40).map(b"".join))
+    def check(data):
+        def run(fn):
+            try:
+                idx, ids = fn(data)
+                return ("ok", idx.shape, idx.tobytes(), tuple(ids))
+            except (KeyError, ValueError, IndexError) as exc:
+                return (type(exc).__name__, exc.args if isinstance(exc, KeyError) else None)
+        assert run(hostio.parse_fasta) == run(fasta.parse_fasta)
+
+    check()
