@@ -1,9 +1,14 @@
+#!/bin/bash
+# Collect the per-round evidence on the GPU box (through gpurun): kernel statistics, PMC passes, bench line.
+#   usage: bash tools/profile_round.sh r01e      -> gpurun_out/{stats,pmc,bench}_<tag>*
+# Copy the summaries you want judged into profiles/ afterwards (see profiles/README.md).
 set -u
+TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/stats_r01e
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_r01e -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/stats_r01e.log 2>&1
+mkdir -p $R/gpurun_out/stats_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/stats_$TAG.log 2>&1
 cd $R
-bash tools/pmc.sh pmc_r01e > gpurun_out/pmc_r01e.log 2>&1
-python bench.py > gpurun_out/bench_r01e.json 2> gpurun_out/bench_r01e.err
-tail -c 1500 gpurun_out/bench_r01e.json
+bash tools/pmc.sh pmc_$TAG > gpurun_out/pmc_$TAG.log 2>&1
+python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+tail -c 1500 gpurun_out/bench_$TAG.json
