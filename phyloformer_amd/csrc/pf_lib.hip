@@ -457,10 +457,13 @@ struct Workspace {
     int G;
 };
 
-int colstats_groups(int B, int P, int Lloc) {
+// Pair groups of k_colstats.  Chosen from the alignment's shape only - never from the batch size - so that
+// the association of the pair sums, and with it every output bit, is the same whatever batch an alignment
+// travels in (a lone 60 x 500 alignment still yields 128 blocks).
+int colstats_groups(int /*B*/, int P, int Lloc) {
     const int chunks = (Lloc + 31) / 32;
-    int G = (1024 + B * chunks - 1) / (B * chunks);
-    G = std::min(G, std::max(1, P / 32));
+    int G = std::max((128 + chunks - 1) / chunks, (P + 639) / 640);   // >= 128 blocks, <= 640 pairs per group
+    G = std::min(G, std::max(1, P / 32));                             // >= 32 pairs per group
     return std::max(1, std::min(G, 32));
 }
 

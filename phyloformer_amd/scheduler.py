@@ -17,9 +17,10 @@ by a wide margin.  This module keeps the GPU fed:
 * ``run_multi_device`` shards the *files* over several GPUs, one process per
   GPU, no collective (alignment-level data parallelism, SURVEY.md §8e way 1).
 
-Every alignment is computed independently inside a launch; batching only changes
-how k_colstats splits the pair sum into groups, i.e. fp32 re-association noise
-(<= 2e-5 on the distances, tests/test_cli_gpu.py), far inside the 1e-4 parity bar.
+Every alignment is computed independently inside a launch and no launch parameter
+that affects the order of a sum depends on the batch size: an alignment's distances
+are bit-identical whatever batch it travels in (tests/test_gpu_parity.py,
+tests/test_cli_gpu.py).
 """
 from __future__ import annotations
 
