@@ -203,3 +203,17 @@ def test_table_embedding_equals_mfma_embedding(engines, golden):
     e.set_option("embed_mfma", 0)
     d0 = e.forward(g["c2_idx"])
     assert np.abs(d0 - d1).max() <= 2e-5
+
+
+def test_workspace_chunking_does_not_change_results(engines, golden):
+    """A batch that does not fit the workspace budget is cut into chunks (pf_set_option "ws_limit_mb");
+    the chunked run returns the same bits."""
+    e = engines("pf")
+    a = np.concatenate([golden("configs.npz")["c2_idx"]] * 6)[:17]          # 17 alignments of 20 x 200
+    whole = e.forward(a)
+    e.set_option("ws_limit_mb", 64)                                           # ~5 alignments per chunk
+    try:
+        chunked = e.forward(a)
+    finally:
+        e.set_option("ws_limit_mb", 24576)
+    assert np.array_equal(whole, chunked)
