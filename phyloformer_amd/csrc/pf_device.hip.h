@@ -899,24 +899,25 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     // The per-pair row-attention matrices are staged through LDS 16 pairs at a time (double-buffered):
     // read straight from L2, every 8-lane group of every wave would fetch them again - 10 KB of L1
     // traffic per 8 tokens against 2 KB of x.
-    f32x4 stg[5];
-    auto stage_load = [&](int pt) {
+    // global_load_lds_dwordx4: 16 bytes per lane go straight from global memory to LDS (destination =
+    // wave-uniform base + lane * 16), no staging registers
+    auto stage = [&](int pt, int buf) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.mrow + ((size_t)b * a.P + pt) * MROW);
         const int n4 = min(16, p1 - pt) * (MROW / 4);
+        float* dst = mst + (size_t)buf * 16 * MROW;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) stg[k] = src[min((int)threadIdx.x + 256 * k, n4 - 1)];
+        for (int k = 0; k < 5; ++k) {
+            const int i = (int)threadIdx.x + 256 * k;
+            __builtin_amdgcn_global_load_lds(src + min(i, n4 - 1), dst + (256 * k + 64 * wave) * 4, 16, 0, 0);
+        }
     };
-    auto stage_store = [&](int buf) {
-        f32x4* dst = reinterpret_cast<f32x4*>(mst + (size_t)buf * 16 * MROW);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) dst[threadIdx.x + 256 * k] = stg[k];
-    };
-    if (p0 < p1) { stage_load(p0); stage_store(0); fetch(p0); }
+    if (p0 < p1) { stage(p0, 0); fetch(p0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int pt = p0; pt < p1; pt += 16, buf ^= 1) {
       const bool more = pt + 16 < p1;
-      if (more) stage_load(pt + 16);                       // lands during this tile's compute
+      if (more) stage(pt + 16, buf ^ 1);                   // lands during this tile's compute
       const float* mt = mst + (size_t)buf * 16 * MROW;
       const int pe = min(pt + 16, p1);
       for (int p = pt; p < pe; ++p) {
@@ -989,7 +990,7 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
             z[3][i] = fmaf(k3, d[i], z[3][i]);
         }
       }
-      if (more) stage_store(buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetch) have landed
       __syncthreads();
     }
     // every wave owns its sites: one partial per (b, g, site), no cross-wave reduction
