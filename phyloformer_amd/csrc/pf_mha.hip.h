@@ -216,21 +216,18 @@ __global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
     const bf16x8* ksrc = a.kp + (size_t)rh * Cpad * 2 + lane;
     const bf16x8* vsrc = a.vp + (size_t)rh * a.ntiles * 64 + lane;
     const int nst = (a.ntiles + MHA_KB - 1) / MHA_KB;
-    bf16x8 pre[5];
-    auto fetch = [&](int st) {
+    // global_load_lds_dwordx4: the five fragment planes of the wave's key tile go straight to LDS
+    // (destination = wave-uniform base + lane * 16), no staging registers
+    auto fetch = [&](int st, int buf) {
         const size_t kt = (size_t)min(st * MHA_KB + w, a.ntiles - 1) * 64;
-        pre[0] = ksrc[kt];
-        pre[1] = ksrc[plane_qk + kt];
-        pre[2] = ksrc[2 * plane_qk + kt];
-        pre[3] = vsrc[kt];
-        pre[4] = vsrc[plane_v + kt];
+        __builtin_amdgcn_global_load_lds(ksrc + kt, &stage[buf][w][0][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(ksrc + plane_qk + kt, &stage[buf][w][1][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(ksrc + 2 * plane_qk + kt, &stage[buf][w][2][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(vsrc + kt, &stage[buf][w][3][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(vsrc + plane_v + kt, &stage[buf][w][4][0], 16, 0, 0);
     };
-    auto commit = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 5; ++p) stage[buf][w][p][lane] = pre[p];
-    };
-    fetch(0);
-    commit(0);
+    fetch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 o;
 #pragma unroll
@@ -238,7 +235,7 @@ __global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
     float m_run = -INFINITY, lsum = 0.f;
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nst) fetch(st + 1);
+        if (st + 1 < nst) fetch(st + 1, buf ^ 1);
         const int ktn = min(MHA_KB, a.ntiles - st * MHA_KB);
         for (int k = 0; k < ktn; ++k) {
             const bf16x8 kh = stage[buf][k][0][2 * t + h], km = stage[buf][k][1][2 * t + h],
@@ -278,7 +275,7 @@ __global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
                 mfma3(o, vh, vl, ph, pl);                  // o[j<8] = O^T[d = kmap(j,h)][query t]
             }
         }
-        if (st + 1 < nst) commit(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     const float l = lsum + pair_other(lsum, h);
