@@ -4,26 +4,31 @@
     python bench.py --gpus N --steps K --warmup W          (N = 1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-A *step* is one pass of the hot path (``pf_forward_device`` /
-``pf_forward_sharded_device``) over one batch of synthetic alignments whose residue
-indices are already resident in HBM.  Workload: BASELINE.json configs[2], the
-headline 60-leaf / 500-site shape, ``pf.ckpt`` weights.
+A *step* is one pass of the hot path (``pf_forward_device`` / ``pf_forward_sharded_device``) over one
+batch of synthetic alignments whose residue indices are already resident in HBM.  Workload:
+BASELINE.json configs[2], the headline 60-leaf / 500-site shape, ``pf.ckpt`` weights.
 
-N > 1 (default ``--shard sites``): the global batch is ``batch x N`` alignments and
-every alignment is *site-sharded* over the N ranks (rank r holds 500/N sites of
-every pair); row-attention statistics are all-reduced once per block and the site
-sums once at the end with RCCL (7 collectives per step).  Per-GPU work is fixed as
-N grows → "weak".  ``--shard alignments`` shards whole alignments instead (no collective).
+N > 1 (default ``--shard sites``): the global batch is ``batch x N`` alignments and every alignment is
+*site-sharded* over the N ranks (rank r holds 500/N sites of every pair); row-attention statistics are
+all-reduced once per block and the site sums once at the end with RCCL (7 collectives per step).
+Per-GPU work is fixed as N grows -> "weak".  ``--shard alignments`` shards whole alignments instead (no
+collective).  The ranks meet through ``phyloformer_amd.rendezvous.TcpGroup`` (standard library: the
+launcher's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT, no torch import in a GPU rank).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel ``k_main``: algorithmic flops / HIP-event time, vs the
-dense bf16 MFMA peak) and ``cpu_baseline`` (the torch op-order port of the reference
-timed on this host's cores; N = 1, rank 0 only).
+Rank 0 prints ONE JSON line (contract in the task statement).  ``value`` is the HBM-resident rate;
+``value_host_buffers`` is the same step through ``pf_forward`` with host buffers (H2D of the indices, D2H of
+the distances and one stream synchronisation per call) - the PCIe-inclusive rate SURVEY.md §8d defines.
+Extra objects: ``roofline`` (dominant kernel ``k_main``: algorithmic flops / HIP-event time vs the dense
+bf16 MFMA peak), ``cpu_baseline`` (torch op-order port of the reference on this host's cores: 1 warm-up +
+3 timed forwards, median, at 60x500 and at 20x200; N = 1, rank 0 only) and ``power`` (rocm-smi samples
+taken during the timed region: the forward runs at the chip's power limit).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -39,9 +44,10 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 FLOPS_MAIN_MID = 65536 + 8192 + 9216 + 640
 FLOPS_MAIN_LAST = 65536 + 8192 + 640 + 128
 FLOPS_ALG_PER_TOKEN = 602240           # whole forward, SURVEY.md §8d
+PMC_FILE = os.path.join("profiles", "pmc_k_main.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -53,18 +59,19 @@ def parse_args():
     ap.add_argument("--shard", choices=["sites", "alignments"], default="sites")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event bracketing of kernels")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples")
     ap.add_argument("--force-dist", action="store_true",
-                    help="test aid: run the N>1 code path (gloo rendezvous, RCCL communicator, 7 all-reduces "
+                    help="test aid: run the N>1 code path (rendezvous, RCCL communicator, 7 all-reduces "
                          "per step) even with one rank")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def pmc_traffic(tokens_per_launch):
     """HBM bytes per k_main launch from the committed PMC passes (profiles/pmc_k_main.json, written by
     tools/pmc.sh on the GPU box: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units,
     FETCH_SIZE doubled for 16-byte-per-lane streaming reads as MI355X_MICROARCH.md prescribes),
-    scaled by tokens if the profiled batch differed.  None if no PMC file is present."""
-    path = os.path.join(REPO, "profiles", "pmc_k_main.json")
+    scaled by tokens if the profiled batch differed.  NOT measured by this run.  None if absent."""
+    path = os.path.join(REPO, PMC_FILE)
     if not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -72,8 +79,9 @@ def pmc_traffic(tokens_per_launch):
     return round(p["hbm_bytes_per_token"] * tokens_per_launch)
 
 
-def cpu_baseline(w, n_seqs, n_sites):
-    """Reference-op-order torch port on the host cores: 1 warm-up (small) + 1 timed forward."""
+def cpu_baseline(w, shapes=((60, 500), (20, 200)), repeats=3):
+    """Reference-op-order torch port on the host cores: per shape one warm-up at the SAME
+    shape, then ``repeats`` timed forwards; the median is reported.  Headline shape first."""
     import torch
     from oracle import pf_oracle_torch
     from phyloformer_amd.msa_sim import simulate_batch
@@ -81,65 +89,97 @@ def cpu_baseline(w, n_seqs, n_sites):
     # 256 hardware threads, where the OpenMP pool oversubscribes) - tests/dev/cpu_threads.py
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    pf_oracle_torch.forward(w.tensors, simulate_batch(1, 20, 100, seed=9)[0])   # thread-pool warm-up
-    idx = simulate_batch(1, n_seqs, n_sites, seed=3)[0]
-    t0 = time.perf_counter()
-    pf_oracle_torch.forward(w.tensors, idx)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "alignments/s", "cores": cores, "kind": "port",
-            "sample": f"1 forward of one {n_seqs}x{n_sites} alignment, torch CPU ops in the "
-                      f"reference's op order ({dt:.1f} s), {torch.get_num_threads()} threads"}
+    legs = []
+    for n_seqs, n_sites in shapes:
+        idx = simulate_batch(1, n_seqs, n_sites, seed=3)[0]
+        pf_oracle_torch.forward(w.tensors, idx)                       # warm-up, same shape
+        times = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            pf_oracle_torch.forward(w.tensors, idx)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        legs.append({"shape": f"{n_seqs}x{n_sites}", "value": round(1.0 / med, 5), "unit": "alignments/s",
+                     "median_s": round(med, 4), "times_s": [round(t, 4) for t in times]})
+    head = legs[0]
+    return {"value": head["value"], "unit": "alignments/s", "cores": cores, "kind": "port",
+            "sample": f"median of {repeats} timed forwards (after 1 warm-up at the same shape) of one "
+                      f"{head['shape']} alignment, torch CPU ops in the reference's op order "
+                      f"({head['median_s']:.2f} s each), {torch.get_num_threads()} threads",
+            "legs": legs}
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+class PowerSampler:
+    """rocm-smi in a side thread (a separate process per sample: nothing touches the GPU queue)."""
 
-    from phyloformer_amd.engine import Engine
-    from phyloformer_amd.msa_sim import simulate_batch
-    from phyloformer_amd.weights import load_weights
+    def __init__(self, period=0.25):
+        self.samples, self._stop, self._period = [], threading.Event(), period
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True,
+                                     timeout=5).stdout
+                pw = re.search(r"Power \(W\): ([0-9.]+)", out)
+                ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+                if pw and ck:
+                    self.samples.append((float(pw.group(1)), int(ck.group(1))))
+            except Exception:  # noqa: BLE001 - evidence only, never fails the bench
+                return
+            self._stop.wait(self._period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=6)
+
+    def summary(self):
+        busy = [s for s in self.samples if s[1] > 500]
+        if not busy:
+            return None
+        pw = sorted(s[0] for s in busy)
+        ck = sorted(s[1] for s in busy)
+        return {"samples": len(busy), "median_w": pw[len(pw) // 2], "median_sclk_mhz": ck[len(ck) // 2],
+                "cap_w": 1400, "max_sclk_mhz": 2400, "source": "rocm-smi during the timed regions"}
+
+
+def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdout):
+    """The rank logic of the benchmark.  ``group``: TcpGroup (or None when world == 1 and no --force-dist);
+    ``make_engine(device)`` returns an object with the Engine interface (tests pass a fake)."""
     from phyloformer_amd import dist as pfdist
+    from phyloformer_amd.msa_sim import simulate_batch
 
     comm_note = None
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
-    w = load_weights(args.ckpt)
-    # PF_BENCH_DEVICE: test aid - put every rank on one device (a 1-GPU box can then exercise the N > 1
-    # launch path; RCCL refuses two ranks on one GPU, which also exercises the fallback below)
-    eng = Engine(w, device=int(os.environ.get("PF_BENCH_DEVICE", local_rank)))
+    eng = make_engine(int(os.environ.get("PF_BENCH_DEVICE", local_rank)))
+    comm = None
     if args.force_dist and world == 1:
         eng.set_option("force_rccl", 1)
-        uid = pfdist.broadcast_bytes(eng.unique_id(), 128, src=0)
-        eng.comm_init(uid, 0, 1)
+        eng.comm_init(eng.unique_id(), 0, 1)
+        comm = eng.comm_info()
     elif world > 1 and args.shard == "sites":
-        # every rank must agree on whether the RCCL communicator came up: if it did not (librccl missing,
-        # init error) on any rank, all of them fall back to sharding whole alignments (no collective) so
-        # the scaling run still measures something, and the line says so
-        import torch
+        # every rank must agree on whether the RCCL communicator came up: if it did not on ANY rank, all of
+        # them tear theirs down and fall back to sharding whole alignments (no collective), so the scaling
+        # run still measures something, and the line says so
         ok, why = 1, ""
         try:
-            pfdist.init_engine_comm(eng)
+            pfdist.init_engine_comm(eng, group)
+            comm = eng.comm_info()
         except Exception as exc:  # noqa: BLE001
             ok, why = 0, f"{type(exc).__name__}: {exc}"
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        reasons = group.allgather((ok, why))
+        if not all(o for o, _ in reasons):
+            eng.comm_destroy()              # pf_forward* must not see a half-built communicator
+            why = next(wy for o, wy in reasons if not o)
             if rank == 0:
-                print(f"bench: RCCL communicator unavailable ({why or 'failed on another rank'}); "
-                      "falling back to --shard alignments", file=sys.stderr)
+                print(f"bench: RCCL communicator unavailable ({why}); falling back to --shard alignments",
+                      file=sys.stderr)
             args.shard = "alignments"
-            comm_note = "site-sharding unavailable (RCCL init failed), alignments sharded instead"
+            comm, comm_note = None, "site-sharding unavailable (RCCL init failed), alignments sharded instead"
 
     N, L = args.n_seqs, args.n_sites
     P = N * (N - 1) // 2
@@ -164,37 +204,46 @@ def main():
         else:
             eng.forward_device(d_idx, B, N, L, d_out)
 
+    def step_host():
+        if args.shard == "sites":
+            return eng.forward_sharded(idx, lo, hi, L)
+        return eng.forward(idx)
+
     def barrier():
         eng.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if group is not None:
+            group.barrier()
+
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        return group.allreduce_max(dt) if group is not None else dt
 
     for _ in range(args.warmup):
         step()
     if not args.no_profile:
         eng.set_option("profile", 2)   # HIP events around every k_main launch only (see header)
         eng.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    sampler = PowerSampler() if (rank == 0 and not args.no_power) else None
+    if sampler:
+        sampler.__enter__()
+    dt = timed(step, args.steps)
     prof = {}
     if not args.no_profile:
         prof["main"] = eng.profile_get("main")
         eng.set_option("profile", 0)
-    out = np.empty((B, P), np.float32)
-    eng.d2h(out, d_out)
-    assert np.isfinite(out).all() and (out > 0).all()
+    result = np.empty((B, P), np.float32)
+    eng.d2h(result, d_out)
+    assert np.isfinite(result).all() and (result > 0).all()
+    # the same step with host buffers: H2D + forward + D2H + synchronisation per call
+    step_host()
+    dt_host = timed(step_host, args.steps)
+    if sampler:
+        sampler.__exit__(None, None, None)
     info = eng.device_info()
 
     total_alignments = (B if args.shard == "sites" else B * world) * args.steps
@@ -205,13 +254,15 @@ def main():
         if prof.get("main", (0, 0))[0]:
             n_main, ms_main = prof["main"]
             avg_s = ms_main / n_main * 1e-3
-            nb = w.n_blocks
+            nb = weights.n_blocks
             flops = tokens_per_launch * ((nb - 1) * FLOPS_MAIN_MID + FLOPS_MAIN_LAST) / nb
             ach = flops / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": "k_main", "achieved": round(ach, 2),
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                     "traffic": pmc_traffic(tokens_per_launch),
+                    "traffic_source": f"{PMC_FILE}: separate rocprofv3 --pmc passes of this build (tools/pmc.sh), "
+                                      "scaled by tokens; not measured by this run",
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_main,
                     "note": "algorithmic flops (1 pass); the split-bf16 scheme issues 3 MFMA passes, "
                             "so frac tops out at 1/3"}
@@ -225,22 +276,52 @@ def main():
                        "global_batch": B if args.shard == "sites" else B * world,
                        "n_seqs": N, "n_sites": L, "parallelism": f"{args.shard}-sharded x{world}",
                        "device": info["name"].strip()},
+            "value_host_buffers": round(total_alignments / dt_host, 3),
+            "value_host_buffers_note": "same steps through pf_forward[_sharded] with host buffers: H2D of the "
+                                       "indices + D2H of the distances + one synchronisation per call "
+                                       "(PCIe-inclusive, SURVEY.md 8d); `value` has the indices resident in HBM",
             "kernel_ms": {k: round(v[1], 3) for k, v in prof.items()} if prof else None,
             "roofline": roof,
+            "power": sampler.summary() if sampler else None,
             "cpu_baseline": None,
         }
+        if comm:
+            line["config"]["rccl"] = comm
         if comm_note:
             line["config"]["note"] = comm_note
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, N, L)
+            line["cpu_baseline"] = cpu_baseline(weights)
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out, flush=True)
     eng.free(d_idx)
     eng.free(d_out)
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+    return value
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    from phyloformer_amd.engine import Engine
+    from phyloformer_amd.rendezvous import TcpGroup
+    from phyloformer_amd.weights import load_weights
+
+    group = TcpGroup(rank, world) if (world > 1 or args.force_dist) else None
+    w = load_weights(args.ckpt)
+    try:
+        run(args, rank, world, local_rank, group, lambda device: Engine(w, device=device), w)
+    finally:
+        if group is not None:
+            group.close()
 
 
 if __name__ == "__main__":

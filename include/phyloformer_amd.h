@@ -105,7 +105,9 @@ const char* pf_last_error(const pf_handle_t* h);
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
 
 /* Forward pass.  idx: host uint8 [B][N][L]; out: host float [B][P].
- * Synchronous: returns after `out` is filled.
+ * Synchronous: returns after `out` is filled.  Never communicates: on a handle that carries a
+ * communicator (pf_comm_init) pf_forward / pf_forward_device still process this rank's own
+ * alignments only (alignment-level data parallelism); collectives belong to pf_forward_sharded*.
  * Errors: PF_EINVAL for B < 1, N < 2, L < 1, N > max_seqs, or an index > 21. */
 int pf_forward(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t L, float* out);
 
@@ -117,8 +119,11 @@ int pf_forward_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N
 
 /* Site-sharded forward: this rank holds sites [l_begin, l_end) of an alignment
  * with L_total sites.  idx: host uint8 [B][N][l_end - l_begin].  Every rank
- * receives the full result in out [B][P].  Requires pf_comm_init when the
- * communicator has more than one rank. */
+ * receives the full result in out [B][P].  The row-attention statistics are all-reduced once per
+ * block and the site sums once at the end (n_blocks + 1 collectives on the handle's stream).
+ * Requires pf_comm_init when the communicator has more than one rank; a partial site range
+ * (l_end - l_begin < L_total) on a handle without a communicator fails with PF_ESTATE instead of
+ * returning partial sums. */
 int pf_forward_sharded(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N,
                        int32_t l_begin, int32_t l_end, int32_t L_total, float* out);
 int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N,
@@ -131,6 +136,10 @@ int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, i
 int pf_comm_unique_id(void* id_out);
 int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t world_size);
 int pf_comm_destroy(pf_handle_t* h);
+/* Which librccl the library resolved ($PF_RCCL_LIB, else $ROCM_PATH/lib, /opt/rocm/lib, then the loader's
+ * search path) and its ncclGetVersion code.  Fails with PF_ERCCL when no librccl bound to the same HIP
+ * runtime as this library can be loaded. */
+int pf_comm_info(char* path_out, size_t path_cap, int32_t* version);
 
 /* Stream / device access for callers that time with HIP events. */
 int pf_synchronize(pf_handle_t* h);
@@ -166,7 +175,7 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
 
 /* Hardware-layout self test: one wave exercises the cross-lane primitives and one
  * MFMA with known operands; `out` receives 2304 floats (layout in
- * phyloformer_amd/csrc/pf_device.hip.h::k_selftest).  tests/test_gpu_selftest.py
+ * phyloformer_amd/csrc/pf_device.hip.h::k_selftest).  tests/test_gpu_parity.py::test_hardware_layout_selftest
  * checks them against the layout the kernels assume. */
 int pf_selftest(pf_handle_t* h, float* out);
 
@@ -205,7 +214,8 @@ int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, i
  *   PF_FASTA_EBYTE     byte outside the alphabet, *detail = the byte   (KeyError, data.py:26)
  *   PF_FASTA_ERAGGED   records of different lengths, *n_out still set  (ValueError from one_hot/stack)
  *   PF_FASTA_ENOHEADER residues before the first '>'                   (IndexError, data.py:26)
- *   PF_FASTA_EEMPTY    no record at all
+ *   PF_FASTA_EEMPTY    no record at all (RuntimeError from one_hot in the reference; so is N records of
+ *                      length 0, which returns PF_OK with *l_out = 0)
  *   PF_FASTA_ECAP      idx_cap or max_seqs too small
  */
 #define PF_FASTA_EBYTE (-16)

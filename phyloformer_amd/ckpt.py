@@ -64,6 +64,16 @@ def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=Fals
     arr = storage
     size = tuple(int(s) for s in size)
     stride = tuple(int(s) for s in stride)
+    storage_offset = int(storage_offset)
+    # as_strided does no bounds checking: a crafted pickle must not be able to read outside its storage
+    if (not isinstance(arr, np.ndarray) or arr.ndim != 1 or len(size) != len(stride) or storage_offset < 0
+            or any(n < 0 for n in size) or any(st < 0 for st in stride)):
+        raise CheckpointError(f"malformed tensor record (offset {storage_offset}, size {size}, stride {stride})")
+    last = storage_offset + sum((n - 1) * st for n, st in zip(size, stride))
+    if all(n > 0 for n in size) and last >= arr.size:
+        raise CheckpointError(f"tensor record reaches element {last} of a storage with {arr.size} elements")
+    if any(n == 0 for n in size):
+        return np.zeros(size, dtype=arr.dtype)
     if len(size) == 0:
         return np.array(arr[storage_offset]).copy()
     itemsize = arr.dtype.itemsize

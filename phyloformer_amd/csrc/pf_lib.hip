@@ -6,7 +6,7 @@
 // (reference: phyloformer/model.py:166-187).
 //
 // Launch sequence for one batch chunk (nb = n_blocks):
-//   k_main<FIRST>                         embedding + pair sum, row stats of block 0
+//   k_embed                               embedding + pair sum, row stats of block 0 (table lookup)
 //   for k in 0..nb-1:
 //       [all-reduce srow]                 site-sharded runs only
 //       k_rowfin(k)      srow -> mrow
@@ -49,15 +49,30 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+std::string g_rccl_path;
+int g_rccl_version = 0;
+
+// Resolution order is fixed so that the library does not depend on what else the process has mapped
+// (a Python process that imported torch carries torch's own bundled librccl / HIP runtime):
+// $PF_RCCL_LIB, then the ROCm installation this library was built against, then the loader's search path.
 bool load_rccl(std::string& err) {
     if (g_rccl.lib) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void* lib = nullptr;
-    for (const char* n : names) {
-        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (lib) break;
+    std::vector<std::string> names;
+    if (const char* env = std::getenv("PF_RCCL_LIB")) names.push_back(env);
+    else {
+        if (const char* rocm = std::getenv("ROCM_PATH")) names.push_back(std::string(rocm) + "/lib/librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
     }
-    if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    void* lib = nullptr;
+    std::string tried;
+    for (const std::string& n : names) {
+        lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+        tried += (tried.empty() ? "" : ", ") + n;
+    }
+    if (!lib) { err = "cannot load librccl (tried " + tried + "): " + dlerror(); return false; }
     g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, PfNcclId, int)>(dlsym(lib, "ncclCommInitRank"));
     g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(
@@ -68,6 +83,20 @@ bool load_rccl(std::string& err) {
         err = "librccl is missing required symbols";
         return false;
     }
+    // RCCL and this library must sit on the same HIP runtime: two runtimes in one process own separate
+    // device contexts and streams.  Compare the file that provides hipGetDeviceCount for each of them.
+    Dl_info rinfo{}, hinfo{}, mine{};
+    dladdr(reinterpret_cast<void*>(g_rccl.GetUniqueId), &rinfo);
+    g_rccl_path = rinfo.dli_fname ? rinfo.dli_fname : "?";
+    void* rccl_hip = dlsym(lib, "hipGetDeviceCount");     // resolved through librccl's own dependency chain
+    if (rccl_hip && dladdr(rccl_hip, &hinfo) && dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &mine) &&
+        hinfo.dli_fname && mine.dli_fname && std::strcmp(hinfo.dli_fname, mine.dli_fname) != 0) {
+        err = std::string("librccl (") + g_rccl_path + ") is bound to the HIP runtime " + hinfo.dli_fname +
+              " but this library uses " + mine.dli_fname + "; set PF_RCCL_LIB to the matching librccl";
+        dlclose(lib);
+        return false;
+    }
+    if (auto getv = reinterpret_cast<int (*)(int*)>(dlsym(lib, "ncclGetVersion"))) getv(&g_rccl_version);
     g_rccl.lib = lib;
     return true;
 }
@@ -212,6 +241,7 @@ struct pf_handle {
     // comm
     void* comm = nullptr;
     int rank = 0, world = 1;
+    bool sharded_call = false;   // set by pf_forward_sharded* for the duration of the call
     // profiling
     std::vector<ProfSlot> pending;
     std::vector<hipEvent_t> free_events;
@@ -535,7 +565,10 @@ int save_tap(pf_handle* h, const std::string& name, const float* dptr, size_t n)
     return PF_OK;
 }
 
+// Collectives belong to the site-sharded entry points only: pf_forward / pf_forward_device on a handle
+// that carries a communicator (alignment-level data parallelism) must not reduce across ranks.
 int allreduce(pf_handle* h, float* buf, size_t count) {
+    if (!h->sharded_call) return PF_OK;
     if (h->world <= 1 && !h->comm) return PF_OK;
     if (!h->comm) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
     ProfScope ps(h, K_ALLREDUCE);
@@ -692,6 +725,10 @@ int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
 int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_begin, int l_end,
                         int L_total, float* d_out) {
     const int Lloc = l_end - l_begin;
+    if (h && h->sharded_call && Lloc < L_total && !h->comm)
+        // a partial site range without a communicator would return partial sums divided by L_total
+        return fail(h, PF_ESTATE, "site range [%d, %d) of %d needs a communicator (pf_comm_init) to be reduced",
+                    l_begin, l_end, L_total);
     if (h && Lloc == 0 && h->world > 1 && B >= 1 && N >= 2 && L_total >= 1) {
         // a rank that owns no sites (L_total < world) still joins every collective with zeros
         HIPCHK(h, hipSetDevice(h->device));
@@ -880,13 +917,27 @@ int pf_forward_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N
 int pf_forward_sharded(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t l_begin,
                        int32_t l_end, int32_t L_total, float* out) {
     if (!h) return PF_EINVAL;
-    return forward_host_impl(h, idx, B, N, l_begin, l_end, L_total, out);
+    h->sharded_call = true;
+    const int rc = forward_host_impl(h, idx, B, N, l_begin, l_end, L_total, out);
+    h->sharded_call = false;
+    return rc;
 }
 
 int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N, int32_t l_begin,
                               int32_t l_end, int32_t L_total, float* d_out) {
     if (!h) return PF_EINVAL;
-    return forward_device_impl(h, d_idx, B, N, l_begin, l_end, L_total, d_out);
+    h->sharded_call = true;
+    const int rc = forward_device_impl(h, d_idx, B, N, l_begin, l_end, L_total, d_out);
+    h->sharded_call = false;
+    return rc;
+}
+
+int pf_comm_info(char* path_out, size_t path_cap, int32_t* version) {
+    std::string err;
+    if (!load_rccl(err)) return fail(nullptr, PF_ERCCL, "%s", err.c_str());
+    if (path_out && path_cap) snprintf(path_out, path_cap, "%s", g_rccl_path.c_str());
+    if (version) *version = g_rccl_version;
+    return PF_OK;
 }
 
 int pf_comm_unique_id(void* id_out) {

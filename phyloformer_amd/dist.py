@@ -11,8 +11,11 @@ Two ways to use several GPUs:
   collectives per forward, issued with ``ncclAllReduce`` on the engine's stream.
 * **alignment sharding** (independent alignments per rank): no collective.
 
-``torch.distributed`` (gloo or nccl backend) is used only for the rendezvous:
-broadcasting the RCCL unique id and the barriers of the benchmark.
+The host-side rendezvous (the 128-byte RCCL unique id, agreement flags, the
+barriers of the benchmark) goes through :class:`phyloformer_amd.rendezvous.TcpGroup`
+(standard library only), so a rank never maps torch's bundled HIP runtime next to
+the one ``libphyloformer_amd.so`` is linked against.  A ``torch.distributed`` group
+is still accepted (gloo tests).
 """
 from __future__ import annotations
 
@@ -44,8 +47,15 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def broadcast_bytes(payload: Optional[bytes], nbytes: int, src: int = 0) -> bytes:
-    """Broadcast a fixed-size byte string over the default torch.distributed group."""
+def broadcast_bytes(payload: Optional[bytes], nbytes: int, src: int = 0, group=None) -> bytes:
+    """Broadcast a fixed-size byte string from rank ``src`` (= 0 for a TcpGroup).
+
+    ``group``: a :class:`~phyloformer_amd.rendezvous.TcpGroup`, or ``None`` for the default
+    ``torch.distributed`` group."""
+    if group is not None:
+        if src != 0:
+            raise ValueError("TcpGroup broadcasts from rank 0")
+        return group.broadcast_bytes(payload, nbytes)
     import torch
     import torch.distributed as dist
     buf = torch.zeros(nbytes, dtype=torch.uint8)
@@ -59,15 +69,35 @@ def broadcast_bytes(payload: Optional[bytes], nbytes: int, src: int = 0) -> byte
     return bytes(buf.cpu().numpy().tobytes())
 
 
-def init_engine_comm(engine) -> Tuple[int, int]:
-    """Create the engine's RCCL communicator across the torch.distributed world."""
-    import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+_NO_ID = bytes(128)      # sentinel: rank 0 could not produce a unique id
+
+
+def init_engine_comm(engine, group=None) -> Tuple[int, int]:
+    """Create the engine's RCCL communicator across ``group`` (TcpGroup) or the torch.distributed world.
+
+    Every rank takes part in the same host collectives whatever happens: if rank 0 cannot produce a
+    unique id (librccl missing or bound to another HIP runtime) it broadcasts an all-zero sentinel and
+    every rank raises the same ``RuntimeError`` - no rank is left waiting in a broadcast that never comes."""
+    if group is not None:
+        rank, world = group.rank, group.world
+    else:
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            engine.comm_init(None, 0, 1)
+            return 0, 1
+        rank, world = dist.get_rank(), dist.get_world_size()
+    if world == 1:
         engine.comm_init(None, 0, 1)
         return 0, 1
-    rank, world = dist.get_rank(), dist.get_world_size()
-    uid = engine.unique_id() if rank == 0 else None
-    uid = broadcast_bytes(uid, 128, src=0)
+    uid, why = None, ""
+    if rank == 0:
+        try:
+            uid = engine.unique_id()
+        except Exception as exc:  # noqa: BLE001 - reported to every rank below
+            uid, why = _NO_ID, f"{type(exc).__name__}: {exc}"
+    uid = broadcast_bytes(uid, 128, src=0, group=group)
+    if uid == _NO_ID:
+        raise RuntimeError("rank 0 could not create an RCCL unique id" + (f" ({why})" if why else ""))
     engine.comm_init(uid, rank, world)
     return rank, world
 

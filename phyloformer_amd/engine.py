@@ -53,6 +53,7 @@ SIGNATURES = {
     "pf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pf_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     "pf_comm_destroy": (C.c_int, [_H]),
+    "pf_comm_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),
     "pf_synchronize": (C.c_int, [_H]),
     "pf_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "pf_device_malloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -247,6 +248,15 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.pf_comm_destroy(self._h))
         self.rank, self.world = 0, 1
+
+    def comm_info(self) -> dict:
+        """Path and version of the librccl the native library resolved (loads it if necessary)."""
+        buf = C.create_string_buffer(512)
+        ver = C.c_int32()
+        rc = self._lib.pf_comm_info(buf, 512, C.byref(ver))
+        if rc != PF_OK:
+            raise EngineError(rc, (self._lib.pf_last_error(None) or b"").decode())
+        return {"library": buf.value.decode(), "version": int(ver.value)}
 
     # -- profiling / debugging --------------------------------------------------------------
     def profile_reset(self):

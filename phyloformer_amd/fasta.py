@@ -9,8 +9,11 @@ alphabet order of data.py:7.
 Parsing rules kept from the reference (data.py:18-26): the file is read as
 bytes, every line is ``strip()``-ed, a line starting with ``>`` opens a record
 whose id is the rest of that line, all other lines are appended to the current
-record, a byte outside the alphabet raises ``KeyError`` and ragged records
-raise ``ValueError``.
+record, a byte outside the alphabet raises ``KeyError``, ragged records raise
+``ValueError``, residues before the first header ``IndexError`` and a file
+without a single residue ``RuntimeError`` (the reference's ``one_hot`` refuses
+the empty float tensor ``torch.tensor([])``, data.py:28).  Pinned against the
+reference itself by ``tests/golden/fasta_edge.json`` (``oracle/gen_golden_fasta.py``).
 """
 from __future__ import annotations
 
@@ -52,13 +55,14 @@ def parse_fasta(data: bytes) -> Tuple[np.ndarray, List[str]]:
                 # the reference indexes sequences[-1] on an empty list here
                 raise IndexError("sequence data before the first '>' header")
             chunks[-1].append(encode_sequence(line))
-    if not chunks:
-        raise ValueError("no sequences found")
     seqs = [np.concatenate(c) if c else np.zeros(0, np.uint8) for c in chunks]
     lengths = {s.size for s in seqs}
-    if len(lengths) != 1:
+    if len(lengths) > 1:
         raise ValueError(
             f"expected sequences of equal length, got lengths {sorted(lengths)}")
+    if not chunks or lengths == {0}:
+        # the reference fails inside one_hot here (RuntimeError): torch.tensor([]) is a float tensor
+        raise RuntimeError("no residues found (empty alignment)")
     return np.stack(seqs).astype(np.uint8), ids
 
 

@@ -31,8 +31,9 @@ def parse_fasta(data: bytes) -> Tuple[np.ndarray, List[str]]:
         raise KeyError(int(detail.value))
     if rc == PF_FASTA_ENOHEADER:
         raise IndexError("sequence data before the first '>' header")
-    if rc == PF_FASTA_EEMPTY:
-        raise ValueError("no sequences found")
+    if rc == PF_FASTA_EEMPTY or (rc == 0 and l.value == 0):
+        # same class as the reference, whose one_hot refuses the empty tensor (data.py:28)
+        raise RuntimeError("no residues found (empty alignment)")
     if rc == PF_FASTA_ERAGGED:
         raise ValueError("expected sequences of equal length")
     if rc != 0:

@@ -59,6 +59,26 @@ def test_rccl_single_rank_communicator(weights, golden):
         e.profile_reset()
         got = e.forward_sharded(a, 0, 200, 200)
         n, _ms = e.profile_get("allreduce")
+        info = e.comm_info()
+        # the plain entry points never communicate, communicator or not (alignment-level data parallelism
+        # on a handle that also serves site-sharded calls)
+        e.profile_reset()
+        plain = e.forward(a)
+        n_plain, _ms = e.profile_get("allreduce")
         e.comm_destroy()
-    assert n == 7
-    assert np.array_equal(got, ref)
+    assert n == 7 and n_plain == 0
+    assert np.array_equal(got, ref) and np.array_equal(plain, ref)
+    assert info["library"].endswith(".so.1") and info["version"] > 20000
+    print("RCCL:", info)
+
+
+def test_partial_site_range_without_communicator_is_refused(weights, golden):
+    """pf_forward_sharded with fewer sites than L_total and no communicator would return partial sums divided
+    by L_total: PF_ESTATE instead."""
+    from phyloformer_amd.engine import Engine, EngineError
+    a = golden("configs.npz")["c2_idx"][:1]
+    with Engine(weights("pf"), 0) as e:
+        with pytest.raises(EngineError) as exc:
+            e.forward_sharded(a[:, :, :120], 0, 120, 200)
+        assert "communicator" in str(exc.value)
+        assert np.isfinite(e.forward(a)).all()          # the handle stays usable

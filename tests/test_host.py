@@ -196,7 +196,8 @@ def test_native_fasta_matches_python_parser(repo):
     (b">a\nARND\n>b\narnd\n", KeyError),          # lower case is not in the alphabet either
     (b">a\nARND\n>b\nARN\n", ValueError),         # ragged
     (b"ARND\n>a\nARND\n", IndexError),            # residues before the first header
-    (b"\n\n", ValueError),                        # nothing
+    (b"\n\n", RuntimeError),                      # nothing: one_hot refuses the empty tensor (data.py:28)
+    (b">a\n>b\n", RuntimeError),                  # records without residues: same
 ])
 def test_native_fasta_errors_match_python_parser(data, exc):
     from phyloformer_amd import fasta, hostio
@@ -206,6 +207,31 @@ def test_native_fasta_errors_match_python_parser(data, exc):
         hostio.parse_fasta(data)
     if exc is KeyError:
         assert e1.value.args == e2.value.args
+
+
+def test_fasta_edge_cases_match_reference_fixtures(repo):
+    """tests/golden/fasta_edge.json holds what the REFERENCE's load_alignment (phyloformer/data.py:11-31)
+    returns or raises on 20 edge-case files (generator: oracle/gen_golden_fasta.py); the Python mirror
+    and the native parser must do the same - same ids, same indices, same exception class."""
+    import base64
+    import json
+    from phyloformer_amd import fasta, hostio
+    with open(os.path.join(repo, "tests", "golden", "fasta_edge.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) >= 20
+    excs = {"KeyError": KeyError, "ValueError": ValueError, "IndexError": IndexError, "RuntimeError": RuntimeError}
+    for name, rec in cases.items():
+        data = base64.b64decode(rec["fasta_b64"])
+        for parse in (fasta.parse_fasta, hostio.parse_fasta):
+            if "raises" in rec:
+                with pytest.raises(excs[rec["raises"]]):
+                    parse(data)
+                    pytest.fail(f"{name}: {parse.__module__} accepted what the reference rejects")
+            else:
+                idx, ids = parse(data)
+                assert ids == rec["ids"], (name, parse.__module__)
+                assert idx.dtype == np.uint8 and idx.tolist() == rec["indices"], (name, parse.__module__)
+                assert list(fasta.one_hot(idx).shape) == rec["shape"]
 
 
 def test_native_phylip_is_byte_identical_to_python_writer():
@@ -238,7 +264,7 @@ def test_native_fasta_parser_agrees_with_python_on_arbitrary_bytes():
             try:
                 idx, ids = fn(data)
                 return ("ok", idx.shape, idx.tobytes(), tuple(ids))
-            except (KeyError, ValueError, IndexError) as exc:
+            except (KeyError, ValueError, IndexError, RuntimeError) as exc:
                 return (type(exc).__name__, exc.args if isinstance(exc, KeyError) else None)
         assert run(hostio.parse_fasta) == run(fasta.parse_fasta)
 

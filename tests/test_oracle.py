@@ -99,3 +99,21 @@ def test_seq_cap_and_bad_input(weights):
         O.forward(w, np.zeros((201, 4), np.uint8))
     with pytest.raises(ValueError):
         O.forward(w, np.full((3, 4), 22, np.uint8))
+
+
+def test_torch_port_matches_goldens(golden, weights, repo):
+    """oracle/pf_oracle_torch.py is the `cpu_baseline` of bench.py: torch CPU ops in the reference's op order
+    and layout.  It must reproduce the reference's own outputs (tests/golden, written by oracle/gen_golden.py
+    from /root/reference) - otherwise the baseline number would describe some other computation."""
+    import torch
+    from oracle import pf_oracle_torch
+    torch.set_num_threads(4)
+    z = golden("configs.npz")
+    for k in range(2):
+        got = pf_oracle_torch.forward(weights("pf").tensors, z["c2_idx"][k])
+        assert np.abs(got - z["c2_dist"][k]).max() <= 2e-6
+    g = golden("e2e_testdata.npz")
+    for ckpt, stem in (("pf_base", "0_20_tips"), ("pf_indel", "1_30_tips"), ("pf", "0_40_tips")):
+        idx, _ids = load_alignment(os.path.join(repo, "data", "testdata", "msas", f"{stem}.fa"))
+        got = pf_oracle_torch.forward(weights(ckpt).tensors, idx)
+        assert np.abs(got - g[f"{ckpt}/{stem}"]).max() <= 2e-6

@@ -1,0 +1,84 @@
+"""Torch-free rendezvous (phyloformer_amd/rendezvous.py) and the agreement logic built on it: real
+processes, world sizes 2 and 3, no GPU."""
+import multiprocessing as mp
+import os
+import sys
+import uuid
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _FakeEngine:
+    """What dist.init_engine_comm needs from an Engine."""
+
+    def __init__(self, rank, fail_uid=False):
+        self.rank_, self.fail_uid, self.inited = rank, fail_uid, None
+
+    def unique_id(self):
+        if self.fail_uid:
+            raise OSError("librccl.so.1: cannot open shared object file")
+        return bytes((7 * i + 1) % 256 for i in range(128))
+
+    def comm_init(self, uid, rank, world):
+        self.inited = (uid, rank, world)
+
+
+def _worker(rank, world, key, tmp, fail_uid, q):
+    sys.path.insert(0, REPO)
+    from phyloformer_amd import dist as pfdist
+    from phyloformer_amd.rendezvous import TcpGroup
+    try:
+        with TcpGroup(rank, world, key=key, directory=tmp, timeout=30) as g:
+            got = g.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 128)
+            ranks = g.allgather(rank)
+            mx, mn = g.allreduce_max(float(rank) + 0.5), g.allreduce_min(float(rank) + 0.5)
+            g.barrier()
+            eng = _FakeEngine(rank, fail_uid=fail_uid)
+            try:
+                pfdist.init_engine_comm(eng, g)
+                comm = ("ok", eng.inited)
+            except RuntimeError as exc:
+                comm = ("error", str(exc))
+            flags = g.allgather(comm[0])
+            q.put((rank, got, ranks, mx, mn, comm, flags))
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, "EXC", repr(exc)))
+
+
+@pytest.mark.parametrize("world,fail_uid", [(2, False), (3, False), (2, True)])
+def test_tcp_group_collectives_and_comm_bootstrap(world, fail_uid, tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "pf_test_" + uuid.uuid4().hex
+    procs = [ctx.Process(target=_worker, args=(r, world, key, str(tmp_path), fail_uid, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, got, ranks, mx, mn, comm, flags in res:
+        assert got == bytes(range(128))
+        assert ranks == list(range(world))
+        assert mx == world - 0.5 and mn == 0.5
+        if fail_uid:
+            # rank 0 broadcast the sentinel instead of leaving its peers in a broadcast that never comes:
+            # every rank raises the same error and they all agree
+            assert comm[0] == "error" and "unique id" in comm[1]
+            assert flags == ["error"] * world
+        else:
+            uid, r, w = comm[1]
+            assert comm[0] == "ok" and (r, w) == (rank, world)
+            assert uid == bytes((7 * i + 1) % 256 for i in range(128))
+    assert not [f for f in os.listdir(tmp_path) if f.startswith(key)], "rendezvous file left behind"
+
+
+def test_tcp_group_single_rank_is_trivial():
+    sys.path.insert(0, REPO)
+    from phyloformer_amd.rendezvous import TcpGroup
+    with TcpGroup(0, 1) as g:
+        assert g.allgather("x") == ["x"] and g.allreduce_max(3.0) == 3.0
+        assert g.broadcast_bytes(b"a" * 128, 128) == b"a" * 128
+        g.barrier()
