@@ -136,6 +136,19 @@ __device__ __forceinline__ float treduce32(float (&v)[32], int t) {
     return v[0];
 }
 
+// Same for 8 values: afterwards every lane j (mod 8) holds the sum over its whole 32-lane half of v[j].
+// Three transposing steps inside each 8-lane group (DPP only), then two plain all-reduce steps across the
+// four groups: 9 shuffle-adds instead of 8 x 5.
+__device__ __forceinline__ float treduce8(float (&v)[8], int t) {
+    treduce_step<4, 0x141>(v, t);
+    treduce_step<2, 0x1B>(v, t);
+    treduce_step<1, 0xB1>(v, t);
+    float r = v[0];
+    r += dpp_f<0x128>(r);      // row_ror:8  (lane ^ 8 inside the 16-lane row)
+    r += swz_xor<16>(r);       // lane ^ 16
+    return r;
+}
+
 // ---- numerics ---------------------------------------------------------------------------
 __device__ __forceinline__ float elu1_fast(float v) {
     // elu(v) + 1 with the hardware exp2 (about 1 ulp): v > 0 ? v + 1 : exp(v)
@@ -318,8 +331,8 @@ struct MainArgs {
     const float* qcol;      // [B][P][Lloc][4]
     const bf16x8* mfrag;    // [B][P][2 To][2 hi/lo][32] row mix M^T (+bias row) as MFMA A fragments
     const float* ctx;       // [B][Lloc][64]
-    float* srow;            // [B][P][72]  out: statistics for the next block's row attn
-    float* out;             // [B][P]      out (last block): sum_l softplus / L_total
+    float* spart;           // [B][P][ntiles][72]  out: per-tile statistics of the next block's row attn
+    float* outpart;         // [B][P][ntiles]      out (last block): per-tile sum_l softplus
     const bf16x8* wimg;     // LDS image (FRAG_END fragments) in global memory
     const float* consts;    // CONST_LEN floats
     const bf16x8* wv_lo;    // [2 T][4 s][64] lo fragments of the next row attn's Wv' (global, L1/L2)
@@ -333,7 +346,6 @@ struct MainArgs {
     unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
     int ablate;             // perf experiments only (results invalid): 1 no x load, 2 no stores,
                             // 4 no next-row phase, 8 no apply phase, 16 no FFN (2 is unused now)
-    float inv_L_total;
 };
 
 enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
@@ -366,9 +378,13 @@ __device__ __forceinline__ bf16x8 zero_frag() {
     return z;
 }
 
-// One wave owns one (alignment, pair) row at a time and walks its sites in
-// tiles of 32 tokens; waves never synchronise with each other after the LDS
-// image is loaded.
+// Work item = one tile of 32 consecutive sites of one (alignment, pair) row.  The B * P * ntiles tiles
+// are cut into one contiguous chunk per wave (a wave streams along rows, as HBM likes it); waves never
+// synchronise with each other after the LDS image is loaded.  Row statistics leave the kernel as one
+// 72-float partial per TILE (summed in fixed order by k_rowfin / k_rowsum), never as per-wave running sums:
+// the result bits do not depend on how the tiles were dealt to waves, i.e. on batch size or grid, and a
+// lone small alignment still spreads over the whole chip (190 rows x 7 tiles of a 20 x 200 alignment are
+// 1,330 work items instead of 190).
 //   MODE_FIRST: x = embedding pair sum;                      -> row stats of block 0
 //   MODE_MID  : row-apply + col-apply + FFN of block k;      -> row stats of block k+1
 //   MODE_LAST : row-apply + col-apply + FFN of the last block -> softplus head, site mean
@@ -395,7 +411,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     const int t = lane & 31;
     const int h = lane >> 5;
     const int ntiles = (a.Lloc + 31) >> 5;
-    const int ntasks = a.B * a.P;
+    const long ntasks = (long)a.B * a.P * ntiles;
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
 #define PF_TICK(k) do { if (a.prof) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; } } while (0)
     if (a.prof) tprev = __builtin_amdgcn_s_memtime();
@@ -407,46 +423,52 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     lds_f32_t lch = lc + 4 * h;
     PF_OPAQUE(wop); PF_OPAQUE(wvp); PF_OPAQUE(qkp); PF_OPAQUE(lch);
 
-    for (int task = blockIdx.x * MAIN_WAVES + wave; task < ntasks; task += gridDim.x * MAIN_WAVES) {
-        const int b = task / a.P;
-        const int p = task - b * a.P;
-        const size_t row0 = (size_t)task * a.Lloc;  // first token of this pair row
-        int ai = 0, aj = 0;
-        if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
-
-        // running row statistics: lane (t, h) owns S_kv[kmap(t, h)] (see treduce32)
-        float s_kv = 0.f, s_q[4], s_k[4], s_out = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s_q[i] = 0.f; s_k[i] = 0.f; }
-
+    {
+        const long nwaves = (long)gridDim.x * MAIN_WAVES;
+        const long chunk = (ntasks + nwaves - 1) / nwaves;
+        const long task0 = (long)(blockIdx.x * MAIN_WAVES + wave) * chunk;
+        const long task1 = min(ntasks, task0 + chunk);
+        int row = (int)(task0 / ntiles);            // b * P + p
+        int tile = (int)(task0 - (long)row * ntiles);
+        int frag_row = -1;                          // the row whose row-mix fragments are in mfr
+        bf16x8 mfr[4];
         // The next tile's residual rows and q' are requested when the FFN of the current tile starts
         // (the residual lives in the GEMM2 accumulators from then on, see below) and land during
         // its ~6 us of matrix work, so a tile never starts by waiting on HBM.
-        // the pair's row-mix fragments are loaded once per row, not once per tile
-        bf16x8 mfr[4];
-        if (MODE != MODE_FIRST) {
-            const bf16x8* mf = a.mfrag + (size_t)task * 128 + t;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mfr[q] = mf[q * 32];
-        }
         f32x4 px[8], pctx[8], pqr, pqc;
-        auto prefetch = [&](int tl) {
-            const int ll = min(tl * 32 + t, a.Lloc - 1);
-            const size_t tk = row0 + ll;
+        auto prefetch = [&](int prow, int ptile) {
+            const int ll = min(ptile * 32 + t, a.Lloc - 1);
+            const size_t tk = (size_t)prow * a.Lloc + ll;
             const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tk * 64 + 4 * h);
 #pragma unroll
             for (int g = 0; g < 8; ++g) px[g] = xp[2 * g];
             pqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
             pqc = *reinterpret_cast<const f32x4*>(a.qcol + tk * 4);
             if (MODE != MODE_FIRST) {
-                const f32x4* cp = reinterpret_cast<const f32x4*>(a.ctx + ((size_t)b * a.Lloc + ll) * 64 + 4 * h);
+                const int pb = prow / a.P;
+                const f32x4* cp = reinterpret_cast<const f32x4*>(a.ctx + ((size_t)pb * a.Lloc + ll) * 64 + 4 * h);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) pctx[g] = cp[2 * g];
             }
         };
-        if (MODE != MODE_FIRST) prefetch(0);
+        if (MODE != MODE_FIRST && task0 < task1) prefetch(row, tile);
 
-        for (int tile = 0; tile < ntiles; ++tile) {
+        for (long task = task0; task < task1; ++task) {
+            const int b = row / a.P;
+            const int p = row - b * a.P;
+            const size_t row0 = (size_t)row * a.Lloc;  // first token of this pair row
+            // position of the tile that follows in this wave's chunk
+            const int ntile = (tile + 1 < ntiles) ? tile + 1 : 0;
+            const int nrow = (tile + 1 < ntiles) ? row : row + 1;
+            int ai = 0, aj = 0;
+            if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
+            if (MODE != MODE_FIRST && row != frag_row) {
+                // the pair's row-mix fragments are loaded once per row, not once per tile
+                const bf16x8* mf = a.mfrag + (size_t)row * 128 + t;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mfr[q] = mf[q * 32];
+                frag_row = row;
+            }
             const int l = tile * 32 + t;
             const bool valid = l < a.Lloc;
             const int lc_ = valid ? l : a.Lloc - 1;  // clamped site for gathers
@@ -475,10 +497,12 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int i = 0; i < 4; ++i) x[4 * g + i] = px[g][i];
                 PF_TICK(0);
                 if (!(a.ablate & 8)) {
-                    f32x16 ya[2];  // starts from the column out_proj bias
-                    load_acc_bias(ya[0], lch + CONST_BOC);
-                    load_acc_bias(ya[1], lch + CONST_BOC + 32);
-                    // ---- row attention apply (block k) incl. its out_proj bias: K = {q'[0..3], 1}
+                    // the accumulators start from the residual itself; both out_proj biases (row + column)
+                    // ride in the K = 4 slot of the row-mix fragments (k_rowfin)
+                    f32x16 ya[2];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) ya[j >> 4][j & 15] = x[j];
+                    // ---- row attention apply (block k) incl. the out_proj biases: K = {q'[0..3], 1}
                     {
                         const f32x4 qr = pqr;
                         float v[8];
@@ -516,7 +540,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) x[j] += ya[j >> 4][j & 15];
+                    for (int j = 0; j < 32; ++j) x[j] = ya[j >> 4][j & 15];
                 }
 
                 PF_TICK(1);
@@ -536,7 +560,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     load_acc_bias(oa[1], lch + CONST_B2 + 32);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
-                    if (tile + 1 < ntiles) prefetch(tile + 1);
+                    if (task + 1 < task1) prefetch(nrow, ntile);
                     PF_TICK(2);
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
@@ -599,7 +623,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         xo[2 * g] = u;
                     }
                 }
-                if (a.ablate & 32) continue;   // perf experiment: copy-only
+                if (a.ablate & 32) { tile = ntile; row = nrow; continue; }   // perf experiment: copy-only
                 f32x16 va[3];
                 {
                     float xn[32];
@@ -638,20 +662,27 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     qn[i] = h ? ot[i] : qk[i];
                     kn[i] = h ? qk[i] : ot[i];
                 }
+                float* sp = a.spart + (size_t)task * SROW;      // this tile's partial statistics
                 {
                     const float vm = valid ? 1.f : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { kn[i] *= vm; s_q[i] = fmaf(vm, qn[i], s_q[i]); s_k[i] += kn[i]; }
+                    for (int i = 0; i < 4; ++i) kn[i] *= vm;
                     // both half-waves hold the same q'; all lanes store (no branch, see above)
                     const size_t stok = valid ? tok : a.trash_tok + t;
                     f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
                     *reinterpret_cast<f32x4*>(a.qrow + stok * 4) = qs;
+                    // S_q | S_k of the tile: lane j (mod 8) ends up with the half-wave sum of value j
+                    float qk8[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { qk8[i] = vm * qn[i]; qk8[4 + i] = kn[i]; }
+                    const float sqk = treduce8(qk8, t);
+                    if (lane < 8) sp[64 + lane] = sqk;
                 }
                 {
                     float kv[32];
 #pragma unroll
                     for (int j = 0; j < 32; ++j) kv[j] = kn[j >> 3] * va[j >> 4][j & 15];   // kn is masked
-                    s_kv += treduce32(kv, t);
+                    sp[kmap(t, h)] = treduce32(kv, t);      // lane (t, h) owns S_kv[kmap(t, h)]
                 }
             } else if (MODE == MODE_LAST) {
                 // ---- head: softplus(w.x + b) summed over sites (model.py:182-185)
@@ -663,7 +694,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int i = 0; i < 4; ++i) z = fmaf(w4[i], x[4 * g + i], z);
                 }
                 z = pair_sum(z) + lc[CONST_HB];
-                if (valid) s_out += softplus20(z);
+                const float so = half32_sum(valid ? softplus20(z) : 0.f);
+                if (lane == 0) a.outpart[task] = so;
                 if (a.store_x_last && valid) {
                     f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
 #pragma unroll
@@ -674,25 +706,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 }
             }
             PF_TICK(4);
+            tile = ntile;
+            row = nrow;
         }
-
-        // ---- reduce over the 32 token lanes of each half-wave and publish ------------------
-        if (MODE != MODE_LAST) {
-            float* sr = a.srow + (size_t)task * SROW;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s_q[i] = half32_sum(s_q[i]); s_k[i] = half32_sum(s_k[i]); }
-            sr[kmap(t, h)] = s_kv;
-            if (lane == 0) {
-                f32x4 u = {s_q[0], s_q[1], s_q[2], s_q[3]};
-                f32x4 w = {s_k[0], s_k[1], s_k[2], s_k[3]};
-                *reinterpret_cast<f32x4*>(sr + 64) = u;
-                *reinterpret_cast<f32x4*>(sr + 68) = w;
-            }
-        } else {
-            s_out = half32_sum(s_out);
-            if (lane == 0) a.out[task] = s_out * a.inv_L_total;
-        }
-        PF_TICK(5);
     }
     if (a.prof && lane == 0) {
 #pragma unroll
@@ -783,24 +799,40 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
 
 // ---- row finalisation: srow -> mrow ------------------------------------------------------
 struct RowFinArgs {
-    const float* srow;   // [B*P][72]
-    float* mrow;         // [B*P][5][64]   fp32 (k_colstats)
-    bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments (k_main)
+    const float* srow;   // [B*P][nparts][72]  statistics, as nparts partial sums per pair (k_main: one per
+                         //                    tile; k_embed / all-reduced: nparts = 1)
+    float* mrow;         // [B*P][5][64]   fp32 (k_colstats): M[h][c] and the row out_proj bias
+    bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments (k_main); K slot 4 carries the row AND
+                         //                    the column out_proj bias (k_main adds both at once)
     const float* woT;    // [64 hd][64 c]  row out_proj, transposed
     const float* bv;     // [64] folded row v bias
     const float* bias;   // [64] row out_proj bias
-    int npairs;
+    const float* bias_col;  // [64] column out_proj bias of the same block
+    int npairs, nparts;
     float L_total;
 };
 
 __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     __shared__ float ctx[4][64];      // 4 pairs per block
     __shared__ float mm[4][5][64];
+    __shared__ float st[4][SROW];
     const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
     const int pr = blockIdx.x * 4 + sub;
     const bool ok = pr < a.npairs;
     if (ok) {
-        const float* s = a.srow + (size_t)pr * SROW;
+        // partial statistics are summed in index order: the association is a function of the shape only
+        const float* sp = a.srow + (size_t)pr * a.nparts * SROW;
+        float acc = 0.f, acc2 = 0.f;
+        for (int i = 0; i < a.nparts; ++i) {
+            acc += sp[i * SROW + c];
+            if (c < 8) acc2 += sp[i * SROW + 64 + c];
+        }
+        st[sub][c] = acc;
+        if (c < 8) st[sub][64 + c] = acc2;
+    }
+    __syncthreads();
+    if (ok) {
+        const float* s = st[sub];
         const int hh = c >> 4;
         const float sk = s[68 + hh], sq = s[64 + hh];
         // (k / sum k)^T v, then q / mean(q): attention.py:183-192
@@ -818,7 +850,7 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
             mm[sub][hh][c] = acc;
         }
         m[4 * 64 + c] = a.bias[c];
-        mm[sub][4][c] = a.bias[c];
+        mm[sub][4][c] = a.bias[c] + a.bias_col[c];
     }
     __syncthreads();
     if (ok) {
@@ -833,6 +865,27 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
         mf[0] = hi;
         mf[32] = lo;
     }
+}
+
+// per-tile partial statistics -> one [72] row per pair (site-sharded runs all-reduce this; debug taps)
+__global__ void k_rowsum(const float* spart, float* srow, int npairs, int nparts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs * SROW) return;
+    const int pr = i / SROW, c = i - pr * SROW;
+    const float* sp = spart + (size_t)pr * nparts * SROW + c;
+    float acc = 0.f;
+    for (int k = 0; k < nparts; ++k) acc += sp[(size_t)k * SROW];
+    srow[i] = acc;
+}
+
+// per-tile softplus sums of the last block -> distances (site mean, model.py:185)
+__global__ void k_outsum(const float* outpart, float* out, int npairs, int nparts, float inv_L_total) {
+    const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= npairs) return;
+    const float* sp = outpart + (size_t)pr * nparts;
+    float acc = 0.f;
+    for (int k = 0; k < nparts; ++k) acc += sp[k];
+    out[pr] = acc * inv_L_total;
 }
 
 // ---- column statistics -------------------------------------------------------------------

@@ -193,6 +193,7 @@ struct BlockDev {
     float* row_woT = nullptr;  // [64][64]
     float* row_bv = nullptr;   // [64]
     float* row_bo = nullptr;   // [64]
+    float* col_bo = nullptr;   // [64] column out_proj bias (rides in the row-mix fragments, k_rowfin)
     float* col_wqk = nullptr;  // [8][64]
     float* col_bqk = nullptr;  // [8]
     float* col_wvT = nullptr;  // [64][64]
@@ -411,6 +412,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         if ((rc = upload(h, woT, &d.row_woT))) return rc;
         if ((rc = upload(h, bv, &d.row_bv))) return rc;
         if ((rc = upload(h, std::vector<float>(r.bo, r.bo + E), &d.row_bo))) return rc;
+        if ((rc = upload(h, std::vector<float>(c.bo, c.bo + E), &d.col_bo))) return rc;
         // ---- column attention of block k
         std::vector<float> cwq, cbq, cwk, cbk, cwv, cbv;
         fold(c.wq, c.bq, c.g, c.b, NH, E, cwq, cbq);
@@ -483,9 +485,10 @@ int ensure_pairs(pf_handle* h, int N) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag;
+    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag, *spart, *outpart;
     int G;
 };
+constexpr int WS_BUFS = 10;
 
 // Pair groups of k_colstats.  Chosen from the alignment's shape only - never from the batch size - so that
 // the association of the pair sums, and with it every output bit, is the same whatever batch an alignment
@@ -497,7 +500,7 @@ int colstats_groups(int /*B*/, int P, int Lloc) {
     return std::max(1, std::min(G, 32));
 }
 
-size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[8]) {
+size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
     const size_t tok = (size_t)B * P * Lloc;
     size_t o = 0;
     off[0] = o; o = align_up(o + (tok + 32) * 64 * 4, 256);              // x (+ 32-token trash area)
@@ -508,11 +511,14 @@ size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[8]) {
     off[5] = o; o = align_up(o + (size_t)B * G * Lloc * CPART * 4, 256); // part
     off[6] = o; o = align_up(o + (size_t)B * Lloc * 64 * 4, 256);        // ctx
     off[7] = o; o = align_up(o + (size_t)B * P * MFRAG_PER_PAIR * 16, 256); // mfrag
+    const size_t ntiles = (size_t)(Lloc + 31) / 32;
+    off[8] = o; o = align_up(o + (size_t)B * P * ntiles * SROW * 4, 256);   // spart: per-tile row statistics
+    off[9] = o; o = align_up(o + (size_t)B * P * ntiles * 4, 256);          // outpart: per-tile head sums
     return o;
 }
 
 int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w) {
-    size_t off[8];
+    size_t off[WS_BUFS];
     w->G = colstats_groups(B, P, Lloc);
     const size_t need = workspace_bytes(B, P, Lloc, w->G, off);
     if (need > h->ws_bytes) {
@@ -525,6 +531,7 @@ int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w) {
     w->mrow = (float*)(h->ws + off[4]); w->part = (float*)(h->ws + off[5]);
     w->ctx = (float*)(h->ws + off[6]);
     w->mfrag = (float*)(h->ws + off[7]);
+    w->spart = (float*)(h->ws + off[8]); w->outpart = (float*)(h->ws + off[9]);
     return PF_OK;
 }
 
@@ -587,8 +594,8 @@ int launch_main(pf_handle* h, const MainArgs& a, int kid) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES));
         attr_set[h->device & 15] = true;
     }
-    const int ntasks = a.B * a.P;
-    const int grid = std::max(1, std::min(h->prop.multiProcessorCount, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
+    const long ntasks = (long)a.B * a.P * ((a.Lloc + 31) / 32);      // one work item per 32-site tile
+    const int grid = (int)std::max<long>(1, std::min<long>(h->prop.multiProcessorCount, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
     ProfScope ps(h, kid);
     hipLaunchKernelGGL(k_main<MODE>, dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->stream, a);
     HIPCHK(h, hipGetLastError());
@@ -606,9 +613,9 @@ struct ShardRun {
 MainArgs main_args(pf_handle* h, const ShardRun& r) {
     MainArgs m{};
     m.x = r.w.x; m.qrow = r.w.qrow; m.qcol = r.w.qcol;
-    m.mfrag = reinterpret_cast<const bf16x8*>(r.w.mfrag); m.ctx = r.w.ctx; m.srow = r.w.srow;
-    m.out = r.d_out; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
-    m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc; m.inv_L_total = 1.0f / (float)r.L_total;
+    m.mfrag = reinterpret_cast<const bf16x8*>(r.w.mfrag); m.ctx = r.w.ctx; m.spart = r.w.spart;
+    m.outpart = r.w.outpart; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
+    m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.trash_tok = (size_t)r.B * r.P * r.Lloc;
     m.ablate = h->ablate;
@@ -644,15 +651,52 @@ int phase_first(pf_handle* h, const ShardRun& r) {
     return PF_OK;
 }
 
-// block k given the (already reduced) row statistics in `srow`
-int phase_block(pf_handle* h, const ShardRun& r, int k, const float* srow) {
+// Row statistics feeding a block: `nparts` partial sums of 72 floats per pair (k_main leaves one per tile,
+// k_embed and the reduced / all-reduced form one).
+struct RowStats { const float* p; int nparts; };
+
+int tiles_of(int Lloc) { return (Lloc + 31) / 32; }
+
+// per-tile partials -> w.srow (one row per pair): what an all-reduce or a debug tap wants
+int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
+    if (rs->p == r.w.srow) return PF_OK;             // already one row per pair, in place
+    const int n = r.B * r.P * SROW;
+    ProfScope ps(h, K_ROWFIN);
+    hipLaunchKernelGGL(k_rowsum, dim3((n + 255) / 256), dim3(256), 0, h->stream, rs->p, r.w.srow, r.B * r.P, rs->nparts);
+    HIPCHK(h, hipGetLastError());
+    *rs = RowStats{r.w.srow, 1};
+    return PF_OK;
+}
+
+// per-tile head sums of the last block -> distances
+int launch_outsum(pf_handle* h, const ShardRun& r) {
+    const int n = r.B * r.P;
+    ProfScope ps(h, K_ROWFIN);
+    hipLaunchKernelGGL(k_outsum, dim3((n + 255) / 256), dim3(256), 0, h->stream, r.w.outpart, r.d_out, n,
+                       tiles_of(r.Lloc), 1.0f / (float)r.L_total);
+    HIPCHK(h, hipGetLastError());
+    return PF_OK;
+}
+
+// where block 0's statistics are after phase_first: one row per pair from k_embed, per-tile partials from
+// the MFMA cross-check path
+RowStats first_stats(pf_handle* h, const ShardRun& r) {
+    return h->embed_mfma ? RowStats{r.w.spart, tiles_of(r.Lloc)} : RowStats{r.w.srow, 1};
+}
+
+// block k given its row statistics (already reduced over ranks in a site-sharded run)
+int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     const BlockDev& d = h->blk[k];
     const Workspace& w = r.w;
     const int B = r.B, P = r.P, Lloc = r.Lloc;
     int rc;
-    if (h->debug_keep && (rc = save_tap(h, "srow" + std::to_string(k), srow, (size_t)B * P * SROW))) return rc;
+    if (h->debug_keep) {
+        if ((rc = launch_rowsum(h, r, &rs))) return rc;
+        if ((rc = save_tap(h, "srow" + std::to_string(k), rs.p, (size_t)B * P * SROW))) return rc;
+    }
     {
-        RowFinArgs a{srow, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag), d.row_woT, d.row_bv, d.row_bo, B * P, (float)r.L_total};
+        RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag), d.row_woT, d.row_bv, d.row_bo, d.col_bo,
+                     B * P, rs.nparts, (float)r.L_total};
         ProfScope ps(h, K_ROWFIN);
         hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
         HIPCHK(h, hipGetLastError());
@@ -695,10 +739,17 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
     if (rc) return rc;
     if ((rc = ensure_pairs(h, N))) return rc;
     if ((rc = phase_first(h, r))) return rc;
+    RowStats rs = first_stats(h, r);
+    const bool reduces = h->sharded_call && (h->world > 1 || h->comm);
     for (int k = 0; k < h->n_blocks; ++k) {
-        if ((rc = allreduce(h, r.w.srow, (size_t)B * r.P * SROW))) return rc;   // site-sharded runs only
-        if ((rc = phase_block(h, r, k, r.w.srow))) return rc;
+        if (reduces) {                                                     // site-sharded runs only
+            if ((rc = launch_rowsum(h, r, &rs))) return rc;
+            if ((rc = allreduce(h, r.w.srow, (size_t)B * r.P * SROW))) return rc;
+        }
+        if ((rc = phase_block(h, r, k, rs))) return rc;
+        rs = RowStats{r.w.spart, tiles_of(Lloc)};
     }
+    if ((rc = launch_outsum(h, r))) return rc;
     return allreduce(h, d_out, (size_t)B * r.P);
 }
 
@@ -716,7 +767,7 @@ int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
 }
 
 int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
-    size_t off[8];
+    size_t off[WS_BUFS];
     const size_t per = workspace_bytes(1, P, Lloc, 32, off);
     int64_t nb = h->ws_limit_bytes / (int64_t)std::max<size_t>(per, 1);
     return (int)std::max<int64_t>(1, std::min<int64_t>(B, nb));
@@ -1081,7 +1132,7 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
         if (hi <= lo) continue;   // an empty rank contributes zeros to both sums
         ShardRun r{};
         r.B = B; r.N = N; r.P = P; r.Lloc = hi - lo; r.L_total = L;
-        size_t off[8];
+        size_t off[WS_BUFS];
         r.w.G = colstats_groups(B, P, r.Lloc);
         const size_t need = workspace_bytes(B, P, r.Lloc, r.w.G, off);
         char* ws = nullptr; uint8_t* di = nullptr; float* dout = nullptr;
@@ -1092,6 +1143,7 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
         r.w.x = (float*)(ws + off[0]); r.w.qrow = (float*)(ws + off[1]); r.w.qcol = (float*)(ws + off[2]);
         r.w.srow = (float*)(ws + off[3]); r.w.mrow = (float*)(ws + off[4]); r.w.part = (float*)(ws + off[5]);
         r.w.ctx = (float*)(ws + off[6]); r.w.mfrag = (float*)(ws + off[7]);
+        r.w.spart = (float*)(ws + off[8]); r.w.outpart = (float*)(ws + off[9]);
         std::vector<uint8_t> local((size_t)B * N * r.Lloc);
         for (int b = 0; b < B; ++b)
             for (int n = 0; n < N; ++n)
@@ -1113,9 +1165,15 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
     };
     for (auto& r : runs) if ((rc = phase_first(h, r))) break;
     for (int k = 0; !rc && k < h->n_blocks; ++k) {
+        for (auto& r : runs) {                                     // every rank reduces its own tiles first
+            RowStats rs = k == 0 ? first_stats(h, r) : RowStats{r.w.spart, tiles_of(r.Lloc)};
+            if ((rc = launch_rowsum(h, r, &rs))) break;
+        }
+        if (rc) break;
         sum_all((size_t)B * P * SROW, false);                      // stands in for all-reduce #k
-        for (auto& r : runs) if ((rc = phase_block(h, r, k, total))) break;
+        for (auto& r : runs) if ((rc = phase_block(h, r, k, RowStats{total, 1}))) break;
     }
+    if (!rc) for (auto& r : runs) if ((rc = launch_outsum(h, r))) break;
     if (!rc) {
         sum_all((size_t)B * P, true);                              // final all-reduce of the site sums
         if (hipMemcpyAsync(out, total, (size_t)B * P * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
