@@ -99,6 +99,8 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "debug_keep" int   1 = keep per-layer activations for pf_debug_read
  *   "force_rccl" int   1 = pf_comm_init creates a real RCCL communicator even for one rank (tests)
  *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)
+ *   "colstats_mfma" int 1 = column statistics with the MFMA formulation (k_colstats2) instead of the VALU
+ *                      kernel (k_colstats): a measured alternative that is not faster; cross-check only
  *   "embed_mfma" int   1 = compute block 0's row statistics with the MFMA kernel (k_main<FIRST>) instead of
  *                      the residue-pair table lookup (k_embed); cross-check only, same results to fp32 noise
  */

@@ -309,16 +309,19 @@ __device__ __forceinline__ void mfma3_zero(f32x16& acc, const bf16x8& a_hi, cons
 
 // LayerNorm without affine over the 64 channels of a token held by lanes (t,0) and (t,1)
 __device__ __forceinline__ void ln_pair(const float (&x)[32], float (&xn)[32]) {
-    float s = 0.f;
+    // four independent partial sums: a single 32-long dependent chain is ~250 cycles of latency that the
+    // one other wave on the SIMD cannot hide
+    float s4[4] = {x[0], x[1], x[2], x[3]};
 #pragma unroll
-    for (int j = 0; j < 32; ++j) s += x[j];
-    const float mean = pair_sum(s) * (1.f / 64.f);
-    float v = 0.f;
+    for (int j = 4; j < 32; ++j) s4[j & 3] += x[j];
+    const float mean = pair_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.f / 64.f);
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         xn[j] = x[j] - mean;
-        v = fmaf(xn[j], xn[j], v);
+        v4[j & 3] = fmaf(xn[j], xn[j], v4[j & 3]);
     }
+    const float v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
     // v_rsq_f32 (1 ulp) instead of sqrt + IEEE division (~25 VALU instructions with the fix-up sequence)
     const float rstd = __builtin_amdgcn_rsqf(pair_sum(v) * (1.f / 64.f) + LN_EPS);
 #pragma unroll
@@ -497,8 +500,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int i = 0; i < 4; ++i) x[4 * g + i] = px[g][i];
                 PF_TICK(0);
                 if (!(a.ablate & 8)) {
-                    // the accumulators start from the residual itself; both out_proj biases (row + column)
-                    // ride in the K = 4 slot of the row-mix fragments (k_rowfin)
+                    // the accumulators start from the residual itself; both out_proj biases ride in the
+                    // row-mix fragments (K slots 4 and 5, k_rowfin)
                     f32x16 ya[2];
 #pragma unroll
                     for (int j = 0; j < 32; ++j) ya[j >> 4][j & 15] = x[j];
@@ -508,8 +511,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         float v[8];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
-                        v[4] = (h == 0) ? 1.f : 0.f;
-                        v[5] = v[6] = v[7] = 0.f;
+                        v[4] = v[5] = (h == 0) ? 1.f : 0.f;   // K slot 4: row out_proj bias, slot 5: column's
+                        v[6] = v[7] = 0.f;
                         bf16x8 qb_hi, qb_lo;
                         split8(v, qb_hi, qb_lo);
                         // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do, so
@@ -801,9 +804,10 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
 struct RowFinArgs {
     const float* srow;   // [B*P][nparts][72]  statistics, as nparts partial sums per pair (k_main: one per
                          //                    tile; k_embed / all-reduced: nparts = 1)
-    float* mrow;         // [B*P][5][64]   fp32 (k_colstats): M[h][c] and the row out_proj bias
-    bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments (k_main); K slot 4 carries the row AND
-                         //                    the column out_proj bias (k_main adds both at once)
+    float* mrow;         // [B*P][5][64]   fp32 M[h][c] and the row out_proj bias (debug tap only; may be NULL)
+    bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments of M^T: K slots 0-3 heads, 4 the row
+                         //                    out_proj bias, 5 the column out_proj bias (k_main sets both B
+                         //                    slots to 1, k_colstats only slot 4)
     const float* woT;    // [64 hd][64 c]  row out_proj, transposed
     const float* bv;     // [64] folded row v bias
     const float* bias;   // [64] row out_proj bias
@@ -814,7 +818,7 @@ struct RowFinArgs {
 
 __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     __shared__ float ctx[4][64];      // 4 pairs per block
-    __shared__ float mm[4][5][64];
+    __shared__ float mm[4][6][64];
     __shared__ float st[4][SROW];
     const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
     const int pr = blockIdx.x * 4 + sub;
@@ -840,25 +844,26 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     }
     __syncthreads();
     if (ok) {
-        float* m = a.mrow + (size_t)pr * MROW;
+        float* m = a.mrow ? a.mrow + (size_t)pr * MROW : nullptr;
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
             float acc = 0.f;
 #pragma unroll
             for (int d = 0; d < 16; ++d) acc = fmaf(a.woT[(16 * hh + d) * 64 + c], ctx[sub][16 * hh + d], acc);
-            m[hh * 64 + c] = acc;
+            if (m) m[hh * 64 + c] = acc;
             mm[sub][hh][c] = acc;
         }
-        m[4 * 64 + c] = a.bias[c];
-        mm[sub][4][c] = a.bias[c] + a.bias_col[c];
+        if (m) m[4 * 64 + c] = a.bias[c];
+        mm[sub][4][c] = a.bias[c];
+        mm[sub][5][c] = a.bias_col[c];
     }
     __syncthreads();
     if (ok) {
-        // A fragments of M^T for k_main's row-apply MFMA: lane t of half 0 holds K slots 0..4
+        // A fragments of M^T for the row-apply MFMA: lane t of half 0 holds K slots 0..5
         const int To = c >> 5, t = c & 31;
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (i < 5) ? mm[sub][i][32 * To + t] : 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = (i < 6) ? mm[sub][i][32 * To + t] : 0.f;
         bf16x8 hi, lo;
         split8(v, hi, lo);
         bf16x8* mf = a.mfrag + (size_t)pr * MFRAG_PER_PAIR + To * 64 + t;
@@ -912,15 +917,7 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane >> 3, cl = lane & 7;
-    int bid = blockIdx.x;
-    const int g = bid % a.G; bid /= a.G;
-    const int chunk = bid % a.nchunks;
-    const int b = bid / a.nchunks;
-    const int l = chunk * 32 + wave * 8 + ts;
-    const bool lvalid = l < a.Lloc;
-    const int lcl = lvalid ? l : a.Lloc - 1;
     const int per = (a.P + a.G - 1) / a.G;
-    const int p0 = g * per, p1 = min(a.P, p0 + per);
 
     float w[8][8];
 #pragma unroll
@@ -934,6 +931,14 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     // after the transposing reduction lane cl holds projection cl (0-3: q', 4-7: k')
     const float bj = a.bqk[cl];
     const bool up2 = (cl & 4) != 0, up1 = (cl & 2) != 0, up0 = (cl & 1) != 0;
+    int bid = blockIdx.x;
+    const int g = bid % a.G; bid /= a.G;
+    const int chunk = bid % a.nchunks;
+    const int b = bid / a.nchunks;
+    const int l = chunk * 32 + wave * 8 + ts;
+    const bool lvalid = l < a.Lloc;
+    const int lcl = lvalid ? l : a.Lloc - 1;
+    const int p0 = g * per, p1 = min(a.P, p0 + per);
     const float vmask = lvalid ? 1.f : 0.f;
     float z[4][8], s_acc = 0.f;
 #pragma unroll
@@ -1060,6 +1065,223 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     }
 }
 
+
+// ---- column statistics on the matrix cores -------------------------------------------------------------
+// One wave = one task (alignment b, chunk of 32 sites, pair group g): it walks the group's pairs with the
+// 32 tokens of a pair row in k_main's layout (lane (t, h) owns 32 channels of site t), so the two dense
+// contractions per token run on MFMA exactly as in k_main - the row-attention apply (K-padded product with
+// the pair's row-mix fragments) and the folded q/k projection (8 of 32 rows) - and only LayerNorm, the
+// activation and Z~[h][c] += k'[h] x~[c] (128 FMAs per lane and pair, the accumulators live in registers
+// for the whole walk) are vector work: 13 instead of 27.5 VALU instructions per token.  The next pair's
+// token rows reach LDS with global_load_lds (double-buffered, no staging registers); each wave reads back
+// only what it loaded itself, so there is no barrier in the loop.
+struct ColStats2Args {
+    const float* x;        // [B][P][Lloc][64]
+    const float* qrow;     // [B][P][Lloc][4]
+    const bf16x8* mfrag;   // [B][P][2 To][2 hi/lo][32]
+    float* qcol;           // [B][P][Lloc][4]  out (+ 32-token trash area)
+    float* part;           // [B][G][Lloc][4*64 + 8]  out: Z~[h][c] | S_q[4] | S_k[4]
+    const bf16x8* wqk;     // folded column q/k rows as MFMA A fragments: [4 s][2 hi/lo][2 kgrp][8 rows]
+    const float* bqk;      // [8]
+    int B, P, Lloc, G, nchunks;
+    size_t trash_tok;
+    unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
+    int ablate;                 // perf experiments only (results invalid): 1 = stage only the first tile, 2 = no math
+};
+constexpr int CS2_THREADS = 512;                       // 8 waves: two per SIMD
+constexpr int CS2_XBUF = 32 * 64 * 4;                  // one tile of x: 8 KB
+constexpr int CS2_MBUF = 128 * 16;                     // one pair's row-mix fragments: 2 KB
+constexpr int CS2_WAVE_LDS = 2 * CS2_XBUF + CS2_MBUF;  // per wave: x double buffer + fragments
+constexpr int CS2_LDS_BYTES = (CS2_THREADS / 64) * CS2_WAVE_LDS + 128 * 16 + 64;
+
+__global__ void __launch_bounds__(CS2_THREADS, 2) k_colstats2(ColStats2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = lane & 31, h = lane >> 5;
+    unsigned char* xbuf = csm + (size_t)wave * CS2_WAVE_LDS;
+    unsigned char* mbuf = xbuf + 2 * CS2_XBUF;
+    bf16x8* qkl = reinterpret_cast<bf16x8*>(csm + (CS2_THREADS / 64) * CS2_WAVE_LDS);
+    float* bql = reinterpret_cast<float*>(qkl + 128);
+    for (int i = threadIdx.x; i < 128; i += CS2_THREADS) qkl[i] = a.wqk[i];
+    if (threadIdx.x < 8) bql[threadIdx.x] = a.bqk[threadIdx.x];
+    __syncthreads();
+
+    const long ntasks = (long)a.B * a.nchunks * a.G;
+    const long task = (long)blockIdx.x * (CS2_THREADS / 64) + wave;
+    if (task >= ntasks) return;
+    // neighbouring waves take neighbouring site chunks of the same pair group: they walk the same pairs
+    // and share the row-mix fragments in L2
+    const int chunk = (int)(task % a.nchunks);
+    const int g = (int)((task / a.nchunks) % a.G);
+    const int b = (int)(task / ((long)a.nchunks * a.G));
+    const int l = chunk * 32 + t;
+    const bool valid = l < a.Lloc;
+    const int lcl = valid ? l : a.Lloc - 1;
+    const int per = (a.P + a.G - 1) / a.G;
+    const int p0 = g * per, p1 = min(a.P, p0 + per);
+    if (p0 >= p1) return;     // (cannot happen with colstats_groups(), which keeps per * (G - 1) < P)
+
+    lds_frag_t qkp = (lds_frag_t)(qkl) + h * 8 + (t & 7);
+    PF_OPAQUE(qkp);
+    float bq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bq[r] = bql[4 * h + r];
+
+    float z[4][32], sq[4], sk[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+        sq[hh] = 0.f; sk[hh] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z[hh][j] = 0.f;
+    }
+    const float vm = valid ? 1.f : 0.f;
+
+    // Staging of one 8 KB tile (32 tokens x 256 B, contiguous in HBM).  DMA instruction k moves the k-th
+    // KB: lane i fetches one 16-byte piece of tokens 4k .. 4k+3 and it lands at LDS k*1024 + i*16, so every
+    // instruction reads 1 KB of consecutive addresses (a per-token 32-byte-per-lane pattern reaches only half
+    // the bandwidth).  Which piece a lane fetches is chosen so that the later ds_read_b128 of lane (t, h) -
+    // piece c16 = 2 g8 + h of token t - is bank-conflict free: piece c16 of token tt of KB k sits in slot
+    //   tt * 16 + ((c16 + 4 (k & 3) + tt) & 15),
+    // which gives the 16 lanes of every ds_read_b128 service group 16 different bank quads.
+    const size_t pair_stride = (size_t)a.Lloc * 64;
+    const float* xb0 = a.x + (size_t)b * a.P * a.Lloc * 64;
+    int src_off[8];                       // per DMA instruction: float offset of this lane's piece inside a pair row
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int tt = lane >> 4;
+        const int c16 = ((lane & 15) - 4 * (k & 3) - tt) & 15;
+        const int site = min(chunk * 32 + 4 * k + tt, a.Lloc - 1);      // tiles past the row end re-read its last site
+        src_off[k] = site * 64 + c16 * 4;
+    }
+    int rd_off[8];                        // per piece g8: byte offset of lane (t, h)'s read inside a buffer
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8)
+        rd_off[g8] = (t >> 2) * 1024 + ((t & 3) * 16 + ((2 * g8 + h + 4 * ((t >> 2) & 3) + (t & 3)) & 15)) * 16;
+    auto stage = [&](int p, int buf) {
+        const float* src = xb0 + (size_t)p * pair_stride;
+        unsigned char* dst = xbuf + (size_t)buf * CS2_XBUF;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4*>(src + src_off[k]), dst + k * 1024, 16, 0, 0);
+    };
+    // the pair's row-mix fragments (2 KB, [2 To][2 hi/lo][32 lanes]) go through LDS too, single-buffered: the
+    // next pair's are requested once this pair's have been read into registers
+    auto stage_frags = [&](int p) {
+        const bf16x8* mf = a.mfrag + ((size_t)b * a.P + p) * 128 + lane;
+        __builtin_amdgcn_global_load_lds(mf, mbuf, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(mf + 64, mbuf + 1024, 16, 0, 0);
+    };
+    f32x4 nqr;
+    auto fetch = [&](int p) {
+        nqr = *reinterpret_cast<const f32x4*>(a.qrow + (((size_t)b * a.P + p) * a.Lloc + lcl) * 4);
+    };
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define PF_TICK(k) do { if (a.prof) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; } } while (0)
+    stage(p0, 0);
+    stage_frags(p0);
+    fetch(p0);
+    int buf = 0;
+    if (a.prof) tprev = __builtin_amdgcn_s_memtime();
+    for (int p = p0; p < p1; ++p, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this pair's tile and fragments have landed in LDS
+        PF_TICK(0);
+        const f32x4 qr = nqr;
+        bf16x8 mfr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mfr[q] = *reinterpret_cast<const bf16x8*>(mbuf + (q * 32 + t) * 16);
+        const int pn = min(p + 1, p1 - 1);
+        if (!(a.ablate & 1)) stage(pn, buf ^ 1);                // next pair: lands during this one's math
+        fetch(pn);
+        if (a.ablate & 2) { sq[0] += qr[0]; continue; }
+        // x' = x + row attention of this block (row out_proj bias in K slot 4; slot 5, the column bias, off)
+        f32x16 ya[2];
+        {
+            const unsigned char* xl = xbuf + (size_t)buf * CS2_XBUF;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(xl + rd_off[g8]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ya[g8 >> 2][4 * (g8 & 3) + i] = u[i];
+            }
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
+            v[4] = (h == 0) ? 1.f : 0.f;
+            v[5] = v[6] = v[7] = 0.f;
+            bf16x8 qb_hi, qb_lo;
+            split8(v, qb_hi, qb_lo);
+#pragma unroll
+            for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo);
+            stage_frags(pn);                                    // mfr is in registers: its LDS slot is free
+        }
+        PF_TICK(1);
+        float xn[32];
+        {
+            float xr[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) xr[j] = ya[j >> 4][j & 15];
+            ln_pair(xr, xn);
+        }
+        PF_TICK(2);
+        // folded q (rows 0-3) and k (rows 4-7) projections: 8 of the 32 output rows are used
+        f32x16 va;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 xb_hi, xb_lo;
+            split8(&xn[8 * s], xb_hi, xb_lo);
+            const bf16x8 q_hi = qkp[(s * 2) * 16], q_lo = qkp[(s * 2 + 1) * 16];
+            if (s == 0) mfma3_zero(va, q_hi, q_lo, xb_hi, xb_lo);
+            else mfma3(va, q_hi, q_lo, xb_hi, xb_lo);
+        }
+        float qk[4], ot[4], qn[4], kn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qk[i] = elu1_fast(va[i] + bq[i]);
+        PF_TICK(3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ot[i] = pair_other(qk[i], h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qn[i] = h ? ot[i] : qk[i];
+            kn[i] = (h ? qk[i] : ot[i]) * vm;
+            sq[i] = fmaf(vm, qn[i], sq[i]);
+            sk[i] += kn[i];
+        }
+        {
+            // branch-free store (both halves write the same 16 bytes; lanes past the end hit the trash area)
+            const size_t stok = valid ? ((size_t)b * a.P + p) * a.Lloc + l : a.trash_tok + t;
+            const f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
+            *reinterpret_cast<f32x4*>(a.qcol + stok * 4) = qs;
+        }
+        PF_TICK(4);
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) z[hh][j] = fmaf(kn[hh], xn[j], z[hh][j]);
+        PF_TICK(5);
+    }
+    if (a.prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, tacc[k]);
+    }
+#undef PF_TICK
+    if (valid) {
+        float* out = a.part + (((size_t)b * a.G + g) * a.Lloc + l) * CPART;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+                const f32x4 u = {z[hh][4 * g8], z[hh][4 * g8 + 1], z[hh][4 * g8 + 2], z[hh][4 * g8 + 3]};
+                *reinterpret_cast<f32x4*>(out + hh * 64 + 8 * g8 + 4 * h) = u;
+            }
+        if (h == 0) {
+            const f32x4 u = {sq[0], sq[1], sq[2], sq[3]}, w = {sk[0], sk[1], sk[2], sk[3]};
+            *reinterpret_cast<f32x4*>(out + 256) = u;
+            *reinterpret_cast<f32x4*>(out + 260) = w;
+        }
+    }
+}
+
 // ---- column finalisation: partials -> ctx --------------------------------------------------
 struct ColFinArgs {
     const float* part;   // [B][G][Lloc][CPART]
@@ -1075,9 +1297,17 @@ __global__ void __launch_bounds__(256) k_colfin(ColFinArgs a) {
     const int site = blockIdx.x;  // b * Lloc + l
     const int b = site / a.Lloc, l = site - b * a.Lloc;
     for (int i = threadIdx.x; i < CPART; i += 256) {
+        // partials are summed in group order (fixed association); four loads in flight per thread
+        const float* pp = a.part + ((size_t)b * a.G * a.Lloc + l) * CPART + i;
+        const size_t gs = (size_t)a.Lloc * CPART;
         float acc = 0.f;
-        for (int g = 0; g < a.G; ++g)
-            acc += a.part[(((size_t)b * a.G + g) * a.Lloc + l) * CPART + i];
+        int g = 0;
+        for (; g + 4 <= a.G; g += 4) {
+            const float v0 = pp[(size_t)g * gs], v1 = pp[(size_t)(g + 1) * gs], v2 = pp[(size_t)(g + 2) * gs],
+                        v3 = pp[(size_t)(g + 3) * gs];
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; g < a.G; ++g) acc += pp[(size_t)g * gs];
         zs[i] = acc;
     }
     __syncthreads();

@@ -156,6 +156,21 @@ void pack_frags3(const float* W, int M, int K, uint16_t* out) {
                 }
 }
 
+// Rows 0..3 = Wq', 4..7 = Wk' (folded, [4][64] each) as MFMA A fragments of an 8-row tile:
+//   out[((s * 2 + hi/lo) * 16 + kgrp * 8 + row) * 8 + i], 128 fragments of 16 bytes
+void pack_qk_frags(const float* wq, const float* wk, uint16_t* qk) {
+    for (int s = 0; s < 4; ++s)
+        for (int kg = 0; kg < 2; ++kg)
+            for (int m = 0; m < 8; ++m)
+                for (int i = 0; i < 8; ++i) {
+                    const int k = kmap_h(8 * s + i, kg);
+                    const float w = (m < 4) ? wq[(size_t)m * E + k] : wk[(size_t)(m - 4) * E + k];
+                    const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+                    qk[(((size_t)s * 2 + 0) * 16 + kg * 8 + m) * 8 + i] = hi;
+                    qk[(((size_t)s * 2 + 1) * 16 + kg * 8 + m) * 8 + i] = lo;
+                }
+}
+
 // Row-statistics operands of one block's row attention, in the layout of the LDS image tail:
 //   [FRAG_WV ..): Wv' hi fragments [2 T][4 s][64];  [FRAG_QK ..): rows 0..7 of [Wq';Wk'] as
 //   [4 s][2 hi/lo][2 kgrp][8 rows];  wv_lo: Wv' lo fragments [2 T][4 s][64] (stays in global).
@@ -172,17 +187,7 @@ void pack_row_stats(const float* wv, const float* wq, const float* wk, uint16_t*
                     img_tail[dst] = full[src];
                     wv_lo[dst] = full[src + 64 * 8];
                 }
-    uint16_t* qk = img_tail + (size_t)(FRAG_QK - FRAG_WV) * 8;
-    for (int s = 0; s < 4; ++s)
-        for (int kg = 0; kg < 2; ++kg)
-            for (int m = 0; m < 8; ++m)
-                for (int i = 0; i < 8; ++i) {
-                    const int k = kmap_h(8 * s + i, kg);
-                    const float w = (m < 4) ? wq[(size_t)m * E + k] : wk[(size_t)(m - 4) * E + k];
-                    const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
-                    qk[(((size_t)s * 2 + 0) * 16 + kg * 8 + m) * 8 + i] = hi;
-                    qk[(((size_t)s * 2 + 1) * 16 + kg * 8 + m) * 8 + i] = lo;
-                }
+    pack_qk_frags(wq, wk, img_tail + (size_t)(FRAG_QK - FRAG_WV) * 8);
 }
 
 struct BlockDev {
@@ -195,6 +200,7 @@ struct BlockDev {
     float* row_bo = nullptr;   // [64]
     float* col_bo = nullptr;   // [64] column out_proj bias (rides in the row-mix fragments, k_rowfin)
     float* col_wqk = nullptr;  // [8][64]
+    float* col_qkfrag = nullptr;  // the same rows as MFMA A fragments (128 x 16 bytes, k_colstats2)
     float* col_bqk = nullptr;  // [8]
     float* col_wvT = nullptr;  // [64][64]
     float* col_bv = nullptr;   // [64]
@@ -226,6 +232,7 @@ struct pf_handle {
     float* table = nullptr;       // [22][64]
     float* pair_table = nullptr;  // [484][72] block-0 row-attention contributions per residue pair (k_embed)
     bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
+    bool colstats_mfma = false;   // option "colstats_mfma": k_colstats2 (MFMA formulation) instead of k_colstats
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
     float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
     std::vector<BlockDev> blk;
@@ -423,6 +430,11 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         std::copy(cwk.begin(), cwk.end(), wqk.begin() + 4 * E);
         for (int i = 0; i < 4; ++i) { bqk[i] = cbq[i]; bqk[4 + i] = cbk[i]; }
         if ((rc = upload(h, wqk, &d.col_wqk))) return rc;
+        {
+            std::vector<uint16_t> qkf((size_t)128 * 8);
+            pack_qk_frags(cwq.data(), cwk.data(), qkf.data());
+            if ((rc = upload(h, qkf, &d.col_qkfrag))) return rc;
+        }
         if ((rc = upload(h, bqk, &d.col_bqk))) return rc;
         std::vector<float> wvT((size_t)E * E);
         for (int hd = 0; hd < E; ++hd)
@@ -494,10 +506,17 @@ constexpr int WS_BUFS = 10;
 // the association of the pair sums, and with it every output bit, is the same whatever batch an alignment
 // travels in (a lone 60 x 500 alignment still yields 128 blocks).
 int colstats_groups(int /*B*/, int P, int Lloc) {
+    // A wave walks its group's pairs one after the other (0.7 us each): the walk length is the kernel's
+    // latency for a lone alignment, but every extra group costs a 33 KB partial per 32-site chunk (HBM write
+    // + read) and a pipeline fill.  Measured at 60 x 500 (tools/colstats_compare.py), 8 / 16 / 32 groups:
+    // 0.91 / 0.98 / 0.99 ms per launch at batch 16, 0.165 / 0.099 / 0.067 ms at batch 1.  The headline is the
+    // batched rate: >= 128 blocks per alignment, <= 640 and >= 32 pairs per group.
     const int chunks = (Lloc + 31) / 32;
-    int G = std::max((128 + chunks - 1) / chunks, (P + 639) / 640);   // >= 128 blocks, <= 640 pairs per group
-    G = std::min(G, std::max(1, P / 32));                             // >= 32 pairs per group
-    return std::max(1, std::min(G, 32));
+    int G = std::max((128 + chunks - 1) / chunks, (P + 639) / 640);
+    G = std::min(G, std::max(1, P / 32));
+    G = std::max(1, std::min(G, 32));
+    while (G > 1 && (long)((P + G - 1) / G) * (G - 1) >= P) --G;   // no empty group
+    return G;
 }
 
 size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
@@ -505,7 +524,7 @@ size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
     size_t o = 0;
     off[0] = o; o = align_up(o + (tok + 32) * 64 * 4, 256);              // x (+ 32-token trash area)
     off[1] = o; o = align_up(o + (tok + 32) * 4 * 4, 256);               // qrow (+ trash)
-    off[2] = o; o = align_up(o + tok * 4 * 4, 256);                      // qcol
+    off[2] = o; o = align_up(o + (tok + 32) * 4 * 4, 256);               // qcol (+ trash)
     off[3] = o; o = align_up(o + (size_t)B * P * SROW * 4, 256);         // srow
     off[4] = o; o = align_up(o + (size_t)B * P * MROW * 4, 256);         // mrow
     off[5] = o; o = align_up(o + (size_t)B * G * Lloc * CPART * 4, 256); // part
@@ -618,8 +637,8 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
     m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.trash_tok = (size_t)r.B * r.P * r.Lloc;
-    m.ablate = h->ablate;
-    m.prof = h->phase_prof;
+    m.ablate = h->ablate >= 64 ? 0 : h->ablate;
+    m.prof = h->ablate == 64 ? nullptr : h->phase_prof;   // ablate = 64: the phase counters belong to k_colstats2
     return m;
 }
 
@@ -695,16 +714,37 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         if ((rc = save_tap(h, "srow" + std::to_string(k), rs.p, (size_t)B * P * SROW))) return rc;
     }
     {
-        RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag), d.row_woT, d.row_bv, d.row_bo, d.col_bo,
+        RowFinArgs a{rs.p, (h->debug_keep || !h->colstats_mfma) ? w.mrow : nullptr, reinterpret_cast<bf16x8*>(w.mfrag),
+                     d.row_woT, d.row_bv, d.row_bo, d.col_bo,
                      B * P, rs.nparts, (float)r.L_total};
         ProfScope ps(h, K_ROWFIN);
         hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
         HIPCHK(h, hipGetLastError());
     }
     {
-        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32};
-        ProfScope ps(h, K_COLSTATS);
-        hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+        if (!h->colstats_mfma) {
+            ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32};
+            ProfScope ps(h, K_COLSTATS);
+            hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+        } else {
+            // experiment (tools/colstats_compare.py): both contractions on MFMA, 13 instead of 27.5 VALU
+            // instructions per token, but no faster (0.96 vs 0.91 ms at batch 16, 0.145 vs 0.067 ms at batch 1)
+            static bool attr_set[16] = {false};
+            if (!attr_set[h->device & 15]) {
+                HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colstats2),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, CS2_LDS_BYTES));
+                attr_set[h->device & 15] = true;
+            }
+            ColStats2Args a{w.x, w.qrow, reinterpret_cast<const bf16x8*>(w.mfrag), w.qcol, w.part,
+                            reinterpret_cast<const bf16x8*>(d.col_qkfrag), d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
+                            (size_t)B * P * Lloc, h->ablate == 64 ? h->phase_prof : nullptr,
+                            h->ablate >= 128 ? (h->ablate >> 7) : 0};
+            const long ntasks = (long)B * a.nchunks * w.G;
+            const int wpb = CS2_THREADS / 64;
+            ProfScope ps(h, K_COLSTATS);
+            hipLaunchKernelGGL(k_colstats2, dim3((unsigned)((ntasks + wpb - 1) / wpb)), dim3(CS2_THREADS), CS2_LDS_BYTES,
+                               h->stream, a);
+        }
         HIPCHK(h, hipGetLastError());
     }
     {
@@ -943,6 +983,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "profile") { drain_profile(h); h->profile = value != 0; h->profile_main_only = value == 2; }
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "embed_mfma") h->embed_mfma = value != 0;
+    else if (k == "colstats_mfma") h->colstats_mfma = value != 0;
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
     else if (k == "phase_prof") {
