@@ -101,6 +101,8 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)
  *   "colstats_mfma" int 1 = column statistics with the MFMA formulation (k_colstats2) instead of the VALU
  *                      kernel (k_colstats): a measured alternative that is not faster; cross-check only
+ *   "materialize_x0" int 1 = k_embed writes x0 = T[a_i] + T[a_j] to HBM and block 0 reads it (round-1 path);
+ *                      default 0: block 0's kernels form it from the embedding table on the fly
  *   "embed_mfma" int   1 = compute block 0's row statistics with the MFMA kernel (k_main<FIRST>) instead of
  *                      the residue-pair table lookup (k_embed); cross-check only, same results to fp32 noise
  */

@@ -351,7 +351,7 @@ struct MainArgs {
                             // 4 no next-row phase, 8 no apply phase, 16 no FFN (2 is unused now)
 };
 
-enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2 };
+enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_MID0 = 3 };
 
 typedef const f32x4 __attribute__((address_space(3)))* lds_f32x4_t;
 __device__ __forceinline__ void load_acc_bias(f32x16& acc, lds_f32_t lds_bias_h) {
@@ -390,6 +390,9 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 // 1,330 work items instead of 190).
 //   MODE_FIRST: x = embedding pair sum;                      -> row stats of block 0
 //   MODE_MID  : row-apply + col-apply + FFN of block k;      -> row stats of block k+1
+//   MODE_MID0 : the same for block 0, whose input x0 = T[a_i] + T[a_j] (model.py:173-175) is formed on the
+//               fly from the 5.6 KB embedding table (L1-resident) instead of being read from HBM: x0 is
+//               never materialised (3.6 GB less written and 2 x 3.6 GB less read per batch of 16)
 //   MODE_LAST : row-apply + col-apply + FFN of the last block -> softplus head, site mean
 template <int MODE>
 __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs a) {
@@ -439,12 +442,20 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         // (the residual lives in the GEMM2 accumulators from then on, see below) and land during
         // its ~6 us of matrix work, so a tile never starts by waiting on HBM.
         f32x4 px[8], pctx[8], pqr, pqc;
+        int pri = 0, prj = 0;                       // MODE_MID0: residues of the next tile's site in both sequences
         auto prefetch = [&](int prow, int ptile) {
             const int ll = min(ptile * 32 + t, a.Lloc - 1);
             const size_t tk = (size_t)prow * a.Lloc + ll;
-            const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tk * 64 + 4 * h);
+            if (MODE == MODE_MID0) {
+                const int pb = prow / a.P, pp = prow - pb * a.P;
+                const uint8_t* ib = a.idx + (size_t)pb * a.N * a.Lloc + ll;
+                pri = ib[(size_t)a.pair_i[pp] * a.Lloc];
+                prj = ib[(size_t)a.pair_j[pp] * a.Lloc];
+            } else {
+                const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tk * 64 + 4 * h);
 #pragma unroll
-            for (int g = 0; g < 8; ++g) px[g] = xp[2 * g];
+                for (int g = 0; g < 8; ++g) px[g] = xp[2 * g];
+            }
             pqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
             pqc = *reinterpret_cast<const f32x4*>(a.qcol + tk * 4);
             if (MODE != MODE_FIRST) {
@@ -494,10 +505,22 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 // lanes past the end of the row hold a copy of the row's last site (clamped address):
                 // finite values, no masking needed - their statistics are multiplied by 0 and their
                 // stores go to the trash area
+                if (MODE == MODE_MID0) {
+                    // embedding lookup + pair expansion: the same fp32 sums k_embed / MODE_FIRST form
+                    const f32x4* ti = reinterpret_cast<const f32x4*>(a.table + pri * 64 + 4 * h);
+                    const f32x4* tj = reinterpret_cast<const f32x4*>(a.table + prj * 64 + 4 * h);
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x4 u = ti[2 * g], w = tj[2 * g];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[4 * g + i] = px[g][i];
+                        for (int i = 0; i < 4; ++i) x[4 * g + i] = u[i] + w[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x[4 * g + i] = px[g][i];
+                }
                 PF_TICK(0);
                 if (!(a.ablate & 8)) {
                     // the accumulators start from the residual itself; both out_proj biases ride in the
@@ -737,7 +760,7 @@ struct EmbedArgs {
     const int16_t* pair_j;
     const float* ptab;       // [484][72]  S_kv contribution (64) | q' (4) | k' (4)
     const float* table;      // [22][64]
-    float* x;                // [B*P][Lloc][64]
+    float* x;                // [B*P][Lloc][64]; NULL = do not materialise x0 (block 0's consumers form it themselves)
     float* qrow;             // [B*P][Lloc][4]
     float* srow;             // [B*P][72]
     int B, N, P, Lloc;
@@ -780,7 +803,7 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
                 acc += s;
                 acce += e;
                 const size_t tok = row0 + l;
-                *reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * cl) = xa + xb;
+                if (a.x) *reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * cl) = xa + xb;
                 if (cl == 0) *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = e;
             }
         }
@@ -895,7 +918,7 @@ __global__ void k_outsum(const float* outpart, float* out, int npairs, int npart
 
 // ---- column statistics -------------------------------------------------------------------
 struct ColStatsArgs {
-    const float* x;      // [B][P][Lloc][64]
+    const float* x;      // [B][P][Lloc][64]   (unused by the block-0 variant, which forms x0 from `table`)
     const float* qrow;   // [B][P][Lloc][4]
     const float* mrow;   // [B][P][5][64]
     float* qcol;         // [B][P][Lloc][4]  out
@@ -903,6 +926,12 @@ struct ColStatsArgs {
     const float* wqk;    // [8][64] folded col q (rows 0-3) and k (rows 4-7)
     const float* bqk;    // [8]
     int B, P, Lloc, G, nchunks;
+    // block 0 only (EMBED): x0[p = (i, j)][l] = table[idx[i][l]] + table[idx[j][l]]
+    const float* table;      // [22][64]
+    const uint8_t* idx;      // [B][N][Lloc]
+    const int16_t* pair_i;   // [P]
+    const int16_t* pair_j;
+    int N;
 };
 constexpr int CPART = 4 * 64 + 8;
 
@@ -912,9 +941,16 @@ constexpr int CPART = 4 * 64 + 8;
 // 16-byte loads per lane).  Applies the row attention on the fly (it is not materialised in HBM), then
 // LayerNorm -> q', k' -> Z~ += k' x~.  Eight lanes per token: three steps per cross-lane reduction and,
 // after the transposing butterfly, exactly one projection per lane - 24 VALU instructions per token.
+template <bool EMBED>
 __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     // two staging buffers of 16 pair matrices (5 x 64 floats each)
     __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
+    __shared__ __attribute__((aligned(16))) float emb[EMBED ? 22 * 64 : 4];
+    if (EMBED) {
+        for (int i = threadIdx.x; i < 22 * 64 / 4; i += 256)
+            reinterpret_cast<f32x4*>(emb)[i] = reinterpret_cast<const f32x4*>(a.table)[i];
+        // visible to all waves after the __syncthreads() that follows the first staging request
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane >> 3, cl = lane & 7;
     const int per = (a.P + a.G - 1) / a.G;
@@ -948,10 +984,18 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
 
     // the next pair's token row and q' are requested one iteration ahead (two ahead measured no better)
     f32x4 nx0, nx1, nqr;
+    int nri = 0, nrj = 0;
     auto fetch = [&](int p) {
-        const size_t tk = ((size_t)b * a.P + min(p, a.P - 1)) * a.Lloc + lcl;
-        nx0 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
-        nx1 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
+        const int pc = min(p, a.P - 1);
+        const size_t tk = ((size_t)b * a.P + pc) * a.Lloc + lcl;
+        if (EMBED) {
+            const uint8_t* ib = a.idx + (size_t)b * a.N * a.Lloc + lcl;
+            nri = ib[(size_t)a.pair_i[pc] * a.Lloc];
+            nrj = ib[(size_t)a.pair_j[pc] * a.Lloc];
+        } else {
+            nx0 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
+            nx1 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
+        }
         nqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
     };
     // The per-pair row-attention matrices are staged through LDS 16 pairs at a time (double-buffered):
@@ -981,7 +1025,16 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
       for (int p = pt; p < pe; ++p) {
         const size_t pr = (size_t)b * a.P + p;
         const size_t tok = pr * a.Lloc + lcl;
-        const f32x4 xv0 = nx0, xv1 = nx1, qr = nqr;
+        f32x4 xv0, xv1;
+        const f32x4 qr = nqr;
+        if (EMBED) {
+            const float* ei = emb + nri * 64 + 8 * cl;
+            const float* ej = emb + nrj * 64 + 8 * cl;
+            xv0 = *reinterpret_cast<const f32x4*>(ei) + *reinterpret_cast<const f32x4*>(ej);
+            xv1 = *reinterpret_cast<const f32x4*>(ei + 4) + *reinterpret_cast<const f32x4*>(ej + 4);
+        } else {
+            xv0 = nx0; xv1 = nx1;
+        }
         fetch(p + 1);
         const float* m = mt + (p - pt) * MROW + 8 * cl;
         f32x4 y0 = *reinterpret_cast<const f32x4*>(m + 4 * 64), y1 = *reinterpret_cast<const f32x4*>(m + 4 * 64 + 4);

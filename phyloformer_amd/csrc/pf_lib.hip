@@ -233,6 +233,7 @@ struct pf_handle {
     float* pair_table = nullptr;  // [484][72] block-0 row-attention contributions per residue pair (k_embed)
     bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
     bool colstats_mfma = false;   // option "colstats_mfma": k_colstats2 (MFMA formulation) instead of k_colstats
+    bool materialize_x0 = false;  // option "materialize_x0": k_embed writes x0 and block 0 reads it (round-1 path)
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
     float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
     std::vector<BlockDev> blk;
@@ -642,6 +643,12 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
     return m;
 }
 
+// Block 0's consumers (k_colstats, k_main) form x0 = T[a_i] + T[a_j] themselves unless the round-1 path is
+// requested; the MFMA cross-check kernels and single-block models keep the materialised x0.
+bool x0_on_the_fly(const pf_handle* h) {
+    return !h->materialize_x0 && !h->embed_mfma && !h->colstats_mfma && h->n_blocks > 1;
+}
+
 // embedding + pair expansion + row statistics of block 0
 int phase_first(pf_handle* h, const ShardRun& r) {
     int rc;
@@ -658,7 +665,9 @@ int phase_first(pf_handle* h, const ShardRun& r) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, EMBED_LDS_BYTES));
             attr_set[h->device & 15] = true;
         }
-        EmbedArgs e{r.d_idx, h->pair_i, h->pair_j, h->pair_table, h->table, r.w.x, r.w.qrow, r.w.srow,
+        // x0 is written only for those who read it: the round-1 consumers or the "x0" debug tap
+        float* x0 = (x0_on_the_fly(h) && !h->debug_keep) ? nullptr : r.w.x;
+        EmbedArgs e{r.d_idx, h->pair_i, h->pair_j, h->pair_table, h->table, x0, r.w.qrow, r.w.srow,
                     r.B, r.N, r.P, r.Lloc};
         const int ntasks = r.B * r.P, wpb = EMBED_THREADS / 64;
         const int grid = std::max(1, std::min(h->prop.multiProcessorCount, (ntasks + wpb - 1) / wpb));
@@ -723,9 +732,13 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     }
     {
         if (!h->colstats_mfma) {
-            ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32};
+            ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
+                           h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
             ProfScope ps(h, K_COLSTATS);
-            hipLaunchKernelGGL(k_colstats, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+            if (k == 0 && x0_on_the_fly(h))
+                hipLaunchKernelGGL(k_colstats<true>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(k_colstats<false>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
         } else {
             // experiment (tools/colstats_compare.py): both contractions on MFMA, 13 instead of 27.5 VALU
             // instructions per token, but no faster (0.96 vs 0.91 ms at batch 16, 0.145 vs 0.067 ms at batch 1)
@@ -762,7 +775,9 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     m.consts = d.consts;
     if (k + 1 < h->n_blocks) {
         m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[k + 1].wv_lo);
-        if ((rc = launch_main<MODE_MID>(h, m, K_MAIN))) return rc;
+        if (k == 0 && x0_on_the_fly(h)) rc = launch_main<MODE_MID0>(h, m, K_MAIN);
+        else rc = launch_main<MODE_MID>(h, m, K_MAIN);
+        if (rc) return rc;
     } else {
         m.wv_lo = nullptr;
         if ((rc = launch_main<MODE_LAST>(h, m, K_MAIN))) return rc;
@@ -984,6 +999,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "embed_mfma") h->embed_mfma = value != 0;
     else if (k == "colstats_mfma") h->colstats_mfma = value != 0;
+    else if (k == "materialize_x0") h->materialize_x0 = value != 0;
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
     else if (k == "phase_prof") {

@@ -1,10 +1,15 @@
 """Neighbour joining (Saitou & Nei 1987) for the ``--trees`` flag of the CLI.
 
 The reference delegates to ``skbio.tree.nj`` (/root/reference/infer_alns.py:62-64,
-120-123); scikit-bio is not installed in this image, so parity of the tree text
-is unpinned.  This is the textbook algorithm with the
-scikit-bio defaults the reference relies on: negative branch lengths are
-clamped to zero and the final three clusters are joined at a trifurcating root.
+120-123); scikit-bio is not installed in this image, so the tree TEXT of skbio
+is unpinned, but the algorithm is pinned against a reference-held neighbour
+joining: FastME ``-m N`` from the reference checkout gives the same topology
+(RF = 0) and, without clamping, the same branch lengths (<= 3e-8) on the reference's own distance
+matrices of all 20 test MSAs (tests/golden/nj_fastme.json,
+tests/test_treecmp.py::test_nj_matches_fastme_nj_goldens).  This is the textbook
+algorithm with the scikit-bio defaults the reference relies on: negative branch
+lengths are clamped to zero and the final three clusters are joined at a
+trifurcating root.
 O(N³) on N ≤ 200 taxa — host work, not on the device path.
 """
 from __future__ import annotations

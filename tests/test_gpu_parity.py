@@ -39,6 +39,33 @@ def test_hardware_layout_selftest(engines):
             assert d2[l, r] == n % 16, (l, r)
 
 
+_ERRORS = {}
+
+
+def _record(case, got, want):
+    """Absolute max error of one parity case; the table is printed and, on the GPU box, written to
+    gpurun_out/parity_errors.json (copied into DESIGN.md section 5)."""
+    err, scale = float(np.abs(got - want).max()), float(np.abs(want).max())
+    _ERRORS[case] = {"max_abs_err": err, "max_abs_ref": scale}
+    print(f"parity {case}: max-abs error {err:.3e} (max |reference| {scale:.3g})")
+    try:
+        import json
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "parity_errors.json"), "w") as fh:
+            json.dump(_ERRORS, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return err, scale
+
+
+def _bound(scale):
+    """The north star's bound is 1e-4 ABSOLUTE on distances; it is applied as such wherever the reference's
+    distances stay below 1 (every in-distribution case).  Out-of-distribution inputs (2-5 sequences, uniformly
+    random residues) drive distances to 10-40 and the reference's own fp32-vs-fp64 gap to 1e-5; there the
+    bound scales with the largest distance."""
+    return TOL * max(1.0, scale)
+
+
 def test_tiny_taps_localise_every_kernel(engines, weights, golden):
     g = golden("taps_tiny.npz")
     w = weights("pf").tensors
@@ -68,7 +95,8 @@ def test_tiny_taps_localise_every_kernel(engines, weights, golden):
             x_in = ref
         # uniform-random residues incl. X and gaps drive |x| to ~130 and distances to ~12; the
         # reference's own fp32-vs-fp64 gap is 1e-5 here, so the bound is relative (1e-4 of 12)
-        assert np.abs(d - g["dist"]).max() <= 1e-4 * np.abs(g["dist"]).max()
+        err, scale = _record("tiny_taps 5x16 random residues", d, g["dist"])
+        assert err <= _bound(scale)
     finally:
         e.set_option("debug_keep", 0)
 
@@ -85,8 +113,9 @@ def test_oracle_parity_small_shapes(engines, weights):
         assert got.shape == want.shape == (2, n * (n - 1) // 2)
         # 2-5 sequences is far outside the training distribution: the residual stream reaches
         # |x| ~ 560 and logits ~ 190 (fp32-vs-fp64 noise of the oracle itself: 5e-6), so the
-        # bound scales with the distances once they exceed 1
-        assert np.abs(got - want).max() <= TOL * max(1.0, float(np.abs(want).max())), (n, l)
+        # bound scales with the distances once they exceed 1 (absolute 1e-4 below)
+        err, scale = _record(f"oracle {n}x{l}{' gapped' if gaps else ''} pf_indel", got, want)
+        assert err <= _bound(scale), (n, l)
 
 
 def test_reference_goldens_all_checkpoints(engines, golden, repo):
@@ -100,6 +129,7 @@ def test_reference_goldens_all_checkpoints(engines, golden, repo):
             err = np.abs(e.forward(idx) - g[f"{ck}/{os.path.basename(f)[:-3]}"]).max()
             worst = max(worst, err)
             assert err <= TOL, (ck, f, err)
+    _ERRORS["reference test MSAs, 20 x 5 checkpoints (worst)"] = {"max_abs_err": float(worst), "max_abs_ref": None}
     print(f"worst max-abs error over 100 reference outputs: {worst:.3e}")
 
 
@@ -107,11 +137,52 @@ def test_config_goldens(engines, golden):
     g = golden("configs.npz")
     e = engines("pf")
     got = e.forward(g["c2_idx"])
-    assert np.abs(got - g["c2_dist"]).max() <= TOL
+    err2, _ = _record("config 2: 20x200 x3, pf", got, g["c2_dist"])
+    assert err2 <= TOL
     got3 = e.forward(g["c3_idx"])                      # headline shape 60 x 500
-    err = np.abs(got3 - g["c3_dist"]).max()
-    print(f"60x500 max-abs error vs reference: {err:.3e}")
+    err, _ = _record("config 3: 60x500, pf (headline)", got3, g["c3_dist"])
     assert err <= TOL
+
+
+def test_config_goldens_more_headline_shape(engines, golden):
+    """Three further 60 x 500 alignments (other seeds, pf.ckpt) and a gapped 60 x 500 one (pf_indel.ckpt),
+    all against the reference's own outputs (oracle/gen_golden.py --only configs_more): absolute 1e-4."""
+    g = golden("configs_more.npz")
+    got = engines("pf").forward(g["c3b_idx"])
+    for k in range(g["c3b_idx"].shape[0]):
+        err, _ = _record(f"60x500 seed 31 #{k}, pf", got[k], g["c3b_dist"][k])
+        assert err <= TOL
+    gotg = engines("pf_indel").forward(g["c3g_idx"])
+    assert (g["c3g_idx"] == 21).any(), "the gapped golden must contain gaps"
+    err, _ = _record("60x500 gapped, pf_indel", gotg, g["c3g_dist"])
+    assert err <= TOL
+
+
+def test_model_surface_one_hot_input_and_squeeze(weights, golden):
+    """The reference's call surface on the GPU path (model.py:166-187): one-hot float input [B, 22, L, N]
+    as infer_alns.py:112 builds it, `torch.squeeze` semantics of the output ([P] for B = 1, [B, P] for a
+    batch, 0-dim for two sequences) - values against the reference's own outputs (batch_small.npz)."""
+    from phyloformer_amd import fasta
+    from phyloformer_amd.model import Phyloformer
+    g = golden("batch_small.npz")
+    m = Phyloformer(weights("pf"), device=0)
+    try:
+        onehot = np.stack([fasta.one_hot(a) for a in g["idx"]]).astype(np.float32)      # [2, 22, L, N]
+        assert onehot.shape == (2, 22, 40, 6)
+        yb = m(onehot)
+        assert yb.shape == g["dist"].shape == (2, 15)
+        err, _ = _record("model(x) one-hot batch 2 x (6x40)", yb, g["dist"])
+        assert err <= TOL
+        y1 = m(onehot[:1])
+        assert y1.shape == (15,) and np.abs(y1 - g["dist"][0]).max() <= TOL          # B = 1 squeezes to [P]
+        y2 = m(fasta.one_hot(g["idx_n2"]).astype(np.float32)[None])
+        assert y2.shape == () == g["dist_n2"].shape                                   # N = 2: 0-dim
+        err2, _ = _record("model(x) N = 2 (0-dim)", y2, g["dist_n2"])
+        assert err2 <= TOL
+        # index input keeps its batch axis, as documented
+        assert m(g["idx"]).shape == (2, 15)
+    finally:
+        m.close()
 
 
 def test_config_goldens_big(engines, golden, repo):
@@ -119,9 +190,8 @@ def test_config_goldens_big(engines, golden, repo):
     if not os.path.exists(path):
         pytest.skip("configs_big.npz not generated")
     g = np.load(path)
-    err4 = np.abs(engines("pf").forward(g["c4_idx"]) - g["c4_dist"]).max()
-    err5 = np.abs(engines("pf_indel").forward(g["c5_idx"]) - g["c5_dist"]).max()
-    print(f"60x2000: {err4:.3e}  200x500 gapped: {err5:.3e}")
+    err4, _ = _record("config 4: 60x2000, pf", engines("pf").forward(g["c4_idx"]), g["c4_dist"])
+    err5, _ = _record("config 5: 200x500 gapped, pf_indel", engines("pf_indel").forward(g["c5_idx"]), g["c5_dist"])
     assert err4 <= TOL and err5 <= TOL
 
 
@@ -217,3 +287,20 @@ def test_workspace_chunking_does_not_change_results(engines, golden):
     finally:
         e.set_option("ws_limit_mb", 24576)
     assert np.array_equal(whole, chunked)
+
+
+def test_alternative_kernel_paths_agree(weights, golden):
+    """Block 0 forms x0 = T[a_i] + T[a_j] on the fly (default) or reads the materialised copy (option
+    materialize_x0): the same fp32 sums, so bit-identical distances.  The MFMA formulation of the column
+    statistics (option colstats_mfma) re-associates them: equal to the default within 2e-5."""
+    from phyloformer_amd.engine import Engine
+    a = golden("configs.npz")["c2_idx"]
+    out = {}
+    for opt in (None, "materialize_x0", "colstats_mfma"):
+        with Engine(weights("pf"), 0) as e:
+            if opt:
+                e.set_option(opt, 1)
+            out[opt] = e.forward(a)
+    assert np.array_equal(out[None], out["materialize_x0"])
+    assert np.abs(out[None] - out["colstats_mfma"]).max() <= 2e-5
+    assert np.abs(out["colstats_mfma"] - golden("configs.npz")["c2_dist"]).max() <= TOL

@@ -56,6 +56,32 @@ def test_nj_recovers_true_trees_from_their_patristic_distances(repo):
         assert treecmp.branch_score(true, est) <= 1e-9
 
 
+def test_nj_matches_fastme_nj_goldens(repo, golden):
+    """`--trees` (infer_alns.py:62-64, 120-123) is `skbio.tree.nj` in the reference; scikit-bio is absent
+    here, but the reference checkout ships FastME, whose `-m N` is the same neighbour joining.
+    tests/golden/nj_fastme.json holds FastME's NJ trees of the reference's own pf.ckpt distances for the 20
+    test MSAs (oracle/gen_golden_nj.py): this implementation must give the same topology (RF = 0) and the
+    same branch lengths (FastME prints 8 decimals)."""
+    import json
+    with open(os.path.join(repo, "tests", "golden", "nj_fastme.json")) as fh:
+        trees = json.load(fh)
+    gold = golden("e2e_testdata.npz")
+    assert len(trees) == 20
+    for stem, nwk in trees.items():
+        _idx, ids = fasta.load_alignment(os.path.join(repo, "data/testdata/msas", stem + ".fa"))
+        # FastME read the "%.10f" PHYLIP text of the matrix
+        dm = np.round(vec_to_matrix(gold[f"pf/{stem}"], len(ids)).astype(np.float64), 10)
+        # FastME keeps negative branch lengths; skbio (and the CLI default) clamp them to zero
+        mine = treecmp.parse_newick(neighbor_joining(dm, ids, clamp_negative=False))
+        ref = treecmp.parse_newick(nwk)
+        assert treecmp.robinson_foulds(ref, mine)[0] == 0, stem
+        assert treecmp.branch_score(ref, mine) <= 1e-7, stem
+        clamped = treecmp.parse_newick(neighbor_joining(dm, ids))
+        assert treecmp.robinson_foulds(ref, clamped)[0] == 0, stem
+        neg = sum(-v for v in treecmp.splits(ref).values() if v < 0)
+        assert treecmp.branch_score(ref, clamped) <= neg + 1e-7, stem
+
+
 def _tree_check(repo, golden, to_tree):
     gold = golden("e2e_testdata.npz")
     rows = []
