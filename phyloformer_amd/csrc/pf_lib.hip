@@ -217,6 +217,9 @@ struct pf_handle {
     int device = 0;
     int n_blocks = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second half-batch of an overlapped site-sharded forward
+    hipStream_t cur = nullptr;      // the stream the forward's launches currently go to (stream or stream2)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     std::string err;
     // options
@@ -242,15 +245,20 @@ struct pf_handle {
     int pair_n = -1;
     int16_t* pair_i = nullptr;
     int16_t* pair_j = nullptr;
-    // workspace
+    // workspace (ws2: second half-batch of an overlapped site-sharded forward)
     size_t ws_bytes = 0;
     char* ws = nullptr;
+    size_t ws2_bytes = 0;
+    char* ws2 = nullptr;
+    bool overlap = true;          // option "overlap": two half-batches on two streams when collectives run
+    int reserve_cus = 8;          // option "reserve_cus": CUs the persistent kernels leave to RCCL then
     uint8_t* d_idx = nullptr; size_t d_idx_bytes = 0;
     float* d_out = nullptr; size_t d_out_bytes = 0;
     // comm
     void* comm = nullptr;
     int rank = 0, world = 1;
     bool sharded_call = false;   // set by pf_forward_sharded* for the duration of the call
+    bool reducing = false;       // this forward issues collectives (persistent kernels leave reserve_cus CUs free)
     // profiling
     std::vector<ProfSlot> pending;
     std::vector<hipEvent_t> free_events;
@@ -537,21 +545,27 @@ size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
     return o;
 }
 
-int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w) {
+int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w, bool second = false) {
     size_t off[WS_BUFS];
     w->G = colstats_groups(B, P, Lloc);
     const size_t need = workspace_bytes(B, P, Lloc, w->G, off);
-    if (need > h->ws_bytes) {
-        if (h->ws) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
-        HIPCHK(h, hipMalloc((void**)&h->ws, need));
-        h->ws_bytes = need;
+    char*& ws = second ? h->ws2 : h->ws;
+    size_t& have = second ? h->ws2_bytes : h->ws_bytes;
+    if (need > have) {
+        if (ws) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+            hipFree(ws); ws = nullptr; have = 0;
+        }
+        HIPCHK(h, hipMalloc((void**)&ws, need));
+        have = need;
     }
-    w->x = (float*)(h->ws + off[0]); w->qrow = (float*)(h->ws + off[1]);
-    w->qcol = (float*)(h->ws + off[2]); w->srow = (float*)(h->ws + off[3]);
-    w->mrow = (float*)(h->ws + off[4]); w->part = (float*)(h->ws + off[5]);
-    w->ctx = (float*)(h->ws + off[6]);
-    w->mfrag = (float*)(h->ws + off[7]);
-    w->spart = (float*)(h->ws + off[8]); w->outpart = (float*)(h->ws + off[9]);
+    w->x = (float*)(ws + off[0]); w->qrow = (float*)(ws + off[1]);
+    w->qcol = (float*)(ws + off[2]); w->srow = (float*)(ws + off[3]);
+    w->mrow = (float*)(ws + off[4]); w->part = (float*)(ws + off[5]);
+    w->ctx = (float*)(ws + off[6]);
+    w->mfrag = (float*)(ws + off[7]);
+    w->spart = (float*)(ws + off[8]); w->outpart = (float*)(ws + off[9]);
     return PF_OK;
 }
 
@@ -566,15 +580,16 @@ struct ProfScope {
     bool on;
     ProfScope(pf_handle* h_, int kid_) : h(h_), kid(kid_) {
         on = h->profile && (!h->profile_main_only || kid_ == K_MAIN);
-        if (on) { a = get_event(h); b = get_event(h); hipEventRecord(a, h->stream); }
+        if (on) { a = get_event(h); b = get_event(h); hipEventRecord(a, h->cur); }
     }
     ~ProfScope() {
-        if (on) { hipEventRecord(b, h->stream); h->pending.push_back({kid, a, b}); }
+        if (on) { hipEventRecord(b, h->cur); h->pending.push_back({kid, a, b}); }
     }
 };
 void drain_profile(pf_handle* h) {
     if (h->pending.empty()) return;
     hipStreamSynchronize(h->stream);
+    if (h->stream2) hipStreamSynchronize(h->stream2);
     for (auto& s : h->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h->prof_n[s.kid]++; h->prof_ms[s.kid] += ms; }
@@ -587,7 +602,7 @@ void drain_profile(pf_handle* h) {
 int save_tap(pf_handle* h, const std::string& name, const float* dptr, size_t n) {
     std::vector<float>& v = h->taps[name];
     v.resize(n);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     HIPCHK(h, hipMemcpy(v.data(), dptr, n * sizeof(float), hipMemcpyDeviceToHost));
     return PF_OK;
 }
@@ -599,7 +614,7 @@ int allreduce(pf_handle* h, float* buf, size_t count) {
     if (h->world <= 1 && !h->comm) return PF_OK;
     if (!h->comm) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
     ProfScope ps(h, K_ALLREDUCE);
-    int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, h->comm, h->stream);
+    int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, h->comm, h->cur);
     if (rc != 0)
         return fail(h, PF_ERCCL, "ncclAllReduce failed: %s",
                     g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
@@ -615,9 +630,10 @@ int launch_main(pf_handle* h, const MainArgs& a, int kid) {
         attr_set[h->device & 15] = true;
     }
     const long ntasks = (long)a.B * a.P * ((a.Lloc + 31) / 32);      // one work item per 32-site tile
-    const int grid = (int)std::max<long>(1, std::min<long>(h->prop.multiProcessorCount, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
+    const int cus = std::max(1, h->prop.multiProcessorCount - (h->reducing ? h->reserve_cus : 0));
+    const int grid = (int)std::max<long>(1, std::min<long>(cus, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
     ProfScope ps(h, kid);
-    hipLaunchKernelGGL(k_main<MODE>, dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->stream, a);
+    hipLaunchKernelGGL(k_main<MODE>, dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->cur, a);
     HIPCHK(h, hipGetLastError());
     return PF_OK;
 }
@@ -672,7 +688,7 @@ int phase_first(pf_handle* h, const ShardRun& r) {
         const int ntasks = r.B * r.P, wpb = EMBED_THREADS / 64;
         const int grid = std::max(1, std::min(h->prop.multiProcessorCount, (ntasks + wpb - 1) / wpb));
         ProfScope ps(h, K_EMBED);
-        hipLaunchKernelGGL(k_embed, dim3(grid), dim3(EMBED_THREADS), EMBED_LDS_BYTES, h->stream, e);
+        hipLaunchKernelGGL(k_embed, dim3(grid), dim3(EMBED_THREADS), EMBED_LDS_BYTES, h->cur, e);
         HIPCHK(h, hipGetLastError());
     }
     if (h->debug_keep) return save_tap(h, "x0", r.w.x, (size_t)r.B * r.P * r.Lloc * 64);
@@ -690,7 +706,7 @@ int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
     if (rs->p == r.w.srow) return PF_OK;             // already one row per pair, in place
     const int n = r.B * r.P * SROW;
     ProfScope ps(h, K_ROWFIN);
-    hipLaunchKernelGGL(k_rowsum, dim3((n + 255) / 256), dim3(256), 0, h->stream, rs->p, r.w.srow, r.B * r.P, rs->nparts);
+    hipLaunchKernelGGL(k_rowsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, rs->p, r.w.srow, r.B * r.P, rs->nparts);
     HIPCHK(h, hipGetLastError());
     *rs = RowStats{r.w.srow, 1};
     return PF_OK;
@@ -700,7 +716,7 @@ int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
 int launch_outsum(pf_handle* h, const ShardRun& r) {
     const int n = r.B * r.P;
     ProfScope ps(h, K_ROWFIN);
-    hipLaunchKernelGGL(k_outsum, dim3((n + 255) / 256), dim3(256), 0, h->stream, r.w.outpart, r.d_out, n,
+    hipLaunchKernelGGL(k_outsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, r.w.outpart, r.d_out, n,
                        tiles_of(r.Lloc), 1.0f / (float)r.L_total);
     HIPCHK(h, hipGetLastError());
     return PF_OK;
@@ -727,7 +743,7 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
                      d.row_woT, d.row_bv, d.row_bo, d.col_bo,
                      B * P, rs.nparts, (float)r.L_total};
         ProfScope ps(h, K_ROWFIN);
-        hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     {
@@ -736,9 +752,9 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
                            h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
             ProfScope ps(h, K_COLSTATS);
             if (k == 0 && x0_on_the_fly(h))
-                hipLaunchKernelGGL(k_colstats<true>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+                hipLaunchKernelGGL(k_colstats<true>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->cur, a);
             else
-                hipLaunchKernelGGL(k_colstats<false>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->stream, a);
+                hipLaunchKernelGGL(k_colstats<false>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->cur, a);
         } else {
             // experiment (tools/colstats_compare.py): both contractions on MFMA, 13 instead of 27.5 VALU
             // instructions per token, but no faster (0.96 vs 0.91 ms at batch 16, 0.145 vs 0.067 ms at batch 1)
@@ -756,14 +772,14 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
             const int wpb = CS2_THREADS / 64;
             ProfScope ps(h, K_COLSTATS);
             hipLaunchKernelGGL(k_colstats2, dim3((unsigned)((ntasks + wpb - 1) / wpb)), dim3(CS2_THREADS), CS2_LDS_BYTES,
-                               h->stream, a);
+                               h->cur, a);
         }
         HIPCHK(h, hipGetLastError());
     }
     {
         ColFinArgs a{w.part, w.ctx, d.col_wvT, d.col_bv, B, Lloc, w.G, (float)P};
         ProfScope ps(h, K_COLFIN);
-        hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     if (h->debug_keep) {
@@ -787,25 +803,80 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
 }
 
 // one batch chunk, everything resident on the device
+// Does this forward issue collectives?  Only the site-sharded entry points on a handle with a communicator.
+bool reduces_now(const pf_handle* h) { return h->sharded_call && (h->world > 1 || h->comm); }
+
+// How a chunk of B alignments is cut for the overlapped schedule: two halves when collectives run.  Every
+// rank must cut identically (one all-reduce sequence per half), so this depends on B and the options only.
+int halves_of(const pf_handle* h, int B) { return (reduces_now(h) && h->overlap && B >= 2) ? 2 : 1; }
+
+int ensure_second_stream(pf_handle* h) {
+    if (h->stream2) return PF_OK;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    return PF_OK;
+}
+
+// One batch chunk, everything resident on the device.
+// Site-sharded runs with >= 2 alignments are cut into two half-batches on two streams: the all-reduce of one
+// half (RCCL kernels on a few CUs; the persistent compute kernels leave `reserve_cus` free) runs beside the
+// column statistics / FFN of the other.  Each half is an independent forward, so the results are those of
+// the serial schedule bit for bit; the collectives double in number (2 x (n_blocks + 1)) and halve in size.
 int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, int L_total, float* d_out) {
-    ShardRun r{};
-    r.d_idx = d_idx; r.d_out = d_out; r.B = B; r.N = N; r.P = N * (N - 1) / 2; r.Lloc = Lloc; r.L_total = L_total;
-    int rc = ensure_workspace(h, B, r.P, Lloc, &r.w);
+    const int P = N * (N - 1) / 2;
+    const bool reduces = reduces_now(h);
+    const int nh = halves_of(h, B);
+    int rc = ensure_pairs(h, N);
     if (rc) return rc;
-    if ((rc = ensure_pairs(h, N))) return rc;
-    if ((rc = phase_first(h, r))) return rc;
-    RowStats rs = first_stats(h, r);
-    const bool reduces = h->sharded_call && (h->world > 1 || h->comm);
-    for (int k = 0; k < h->n_blocks; ++k) {
-        if (reduces) {                                                     // site-sharded runs only
-            if ((rc = launch_rowsum(h, r, &rs))) return rc;
-            if ((rc = allreduce(h, r.w.srow, (size_t)B * r.P * SROW))) return rc;
-        }
-        if ((rc = phase_block(h, r, k, rs))) return rc;
-        rs = RowStats{r.w.spart, tiles_of(Lloc)};
+    ShardRun r[2]{};
+    RowStats rs[2];
+    hipStream_t st[2] = {h->stream, h->stream};
+    int b0 = 0;
+    for (int i = 0; i < nh; ++i) {
+        const int nb = (nh == 2) ? (i == 0 ? (B + 1) / 2 : B / 2) : B;
+        r[i].d_idx = d_idx + (size_t)b0 * N * Lloc; r[i].d_out = d_out + (size_t)b0 * P;
+        r[i].B = nb; r[i].N = N; r[i].P = P; r[i].Lloc = Lloc; r[i].L_total = L_total;
+        if ((rc = ensure_workspace(h, nb, P, Lloc, &r[i].w, i == 1))) return rc;
+        b0 += nb;
     }
-    if ((rc = launch_outsum(h, r))) return rc;
-    return allreduce(h, d_out, (size_t)B * r.P);
+    if (nh == 2) {
+        if ((rc = ensure_second_stream(h))) return rc;
+        st[1] = h->stream2;
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));          // inputs were produced on the main stream
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    }
+    h->reducing = reduces;
+    auto finish = [&](int code) {
+        h->cur = h->stream;
+        h->reducing = false;
+        return code;
+    };
+    for (int i = 0; i < nh; ++i) {
+        h->cur = st[i];
+        if ((rc = phase_first(h, r[i]))) return finish(rc);
+        rs[i] = first_stats(h, r[i]);
+    }
+    for (int k = 0; k < h->n_blocks; ++k)
+        for (int i = 0; i < nh; ++i) {
+            h->cur = st[i];
+            if (reduces) {                                                 // site-sharded runs only
+                if ((rc = launch_rowsum(h, r[i], &rs[i]))) return finish(rc);
+                if ((rc = allreduce(h, r[i].w.srow, (size_t)r[i].B * P * SROW))) return finish(rc);
+            }
+            if ((rc = phase_block(h, r[i], k, rs[i]))) return finish(rc);
+            rs[i] = RowStats{r[i].w.spart, tiles_of(Lloc)};
+        }
+    for (int i = 0; i < nh; ++i) {
+        h->cur = st[i];
+        if ((rc = launch_outsum(h, r[i]))) return finish(rc);
+        if ((rc = allreduce(h, r[i].d_out, (size_t)r[i].B * P))) return finish(rc);
+    }
+    if (nh == 2) {
+        HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));         // the caller continues on the main stream
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    }
+    return finish(PF_OK);
 }
 
 int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
@@ -836,22 +907,30 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
         return fail(h, PF_ESTATE, "site range [%d, %d) of %d needs a communicator (pf_comm_init) to be reduced",
                     l_begin, l_end, L_total);
     if (h && Lloc == 0 && h->world > 1 && B >= 1 && N >= 2 && L_total >= 1) {
-        // a rank that owns no sites (L_total < world) still joins every collective with zeros
+        // a rank that owns no sites (L_total < world) still joins every collective with zeros: the same
+        // chunks, the same halves and the same counts as its peers issue (forward_chunk)
         HIPCHK(h, hipSetDevice(h->device));
         const int P0 = N * (N - 1) / 2;
-        const int cb0 = chunk_batch(h, B, P0, (L_total + h->world - 1) / h->world);   // same chunks as the peers
+        const int cb0 = chunk_batch(h, B, P0, (L_total + h->world - 1) / h->world);
         for (int b0 = 0; b0 < B; b0 += cb0) {
             const int nb0 = std::min(cb0, B - b0);
             Workspace w0;
             int rc0 = ensure_workspace(h, nb0, P0, 1, &w0);
             if (rc0) return rc0;
-            const size_t ns = (size_t)nb0 * P0 * SROW;
-            for (int k = 0; k < h->n_blocks; ++k) {
-                HIPCHK(h, hipMemsetAsync(w0.srow, 0, ns * sizeof(float), h->stream));
-                if ((rc0 = allreduce(h, w0.srow, ns))) return rc0;
-            }
+            const int nh = halves_of(h, nb0);
+            const int hb[2] = {nh == 2 ? (nb0 + 1) / 2 : nb0, nh == 2 ? nb0 / 2 : 0};
             HIPCHK(h, hipMemsetAsync(d_out + (size_t)b0 * P0, 0, (size_t)nb0 * P0 * sizeof(float), h->stream));
-            if ((rc0 = allreduce(h, d_out + (size_t)b0 * P0, (size_t)nb0 * P0))) return rc0;
+            for (int k = 0; k < h->n_blocks; ++k)
+                for (int i = 0; i < nh; ++i) {
+                    const size_t ns = (size_t)hb[i] * P0 * SROW;
+                    HIPCHK(h, hipMemsetAsync(w0.srow, 0, ns * sizeof(float), h->stream));
+                    if ((rc0 = allreduce(h, w0.srow, ns))) return rc0;
+                }
+            size_t o = (size_t)b0 * P0;
+            for (int i = 0; i < nh; ++i) {
+                if ((rc0 = allreduce(h, d_out + o, (size_t)hb[i] * P0))) return rc0;
+                o += (size_t)hb[i] * P0;
+            }
         }
         return PF_OK;
     }
@@ -936,6 +1015,7 @@ static int open_device(int device, pf_handle** out) {
             break;
         }
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        h->cur = h->stream;
     } while (0);
     if (rc) { pf_destroy(h); return rc; }
     *out = h;
@@ -982,6 +1062,10 @@ int pf_destroy(pf_handle_t* h) {
     if (h->pair_i) hipFree(h->pair_i);
     if (h->pair_j) hipFree(h->pair_j);
     if (h->ws) hipFree(h->ws);
+    if (h->ws2) hipFree(h->ws2);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->d_idx) hipFree(h->d_idx);
     if (h->d_out) hipFree(h->d_out);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1000,6 +1084,8 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "embed_mfma") h->embed_mfma = value != 0;
     else if (k == "colstats_mfma") h->colstats_mfma = value != 0;
     else if (k == "materialize_x0") h->materialize_x0 = value != 0;
+    else if (k == "overlap") h->overlap = value != 0;
+    else if (k == "reserve_cus") h->reserve_cus = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128));
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
     else if (k == "phase_prof") {

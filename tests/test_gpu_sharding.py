@@ -46,8 +46,9 @@ def test_config4_60x2000_eight_shards(engines, repo):
 
 
 def test_rccl_single_rank_communicator(weights, golden):
-    """dlopen(librccl), ncclGetUniqueId/CommInitRank/AllReduce on the engine's stream with one rank:
-    the 7 collectives of a sharded forward must leave the result unchanged."""
+    """dlopen(librccl), ncclGetUniqueId/CommInitRank/AllReduce on the engine's streams with one rank:
+    the collectives of a sharded forward (7 per half-batch, two halves for this batch of two) must leave the
+    result unchanged."""
     from phyloformer_amd.engine import Engine
     g = golden("configs.npz")
     a = g["c2_idx"][:2]
@@ -66,7 +67,7 @@ def test_rccl_single_rank_communicator(weights, golden):
         plain = e.forward(a)
         n_plain, _ms = e.profile_get("allreduce")
         e.comm_destroy()
-    assert n == 7 and n_plain == 0
+    assert n == 14 and n_plain == 0
     assert np.array_equal(got, ref) and np.array_equal(plain, ref)
     assert info["library"].endswith(".so.1") and info["version"] > 20000
     print("RCCL:", info)
@@ -82,3 +83,31 @@ def test_partial_site_range_without_communicator_is_refused(weights, golden):
             e.forward_sharded(a[:, :, :120], 0, 120, 200)
         assert "communicator" in str(exc.value)
         assert np.isfinite(e.forward(a)).all()          # the handle stays usable
+
+
+def test_overlapped_half_batches_equal_serial_schedule(weights, golden):
+    """Site-sharded forwards with >= 2 alignments run as two half-batches on two streams so that the
+    all-reduce of one half overlaps the compute of the other (option "overlap", default on).  With a real
+    (single-rank) RCCL communicator: bit-identical to the serial schedule, 2 x (n_blocks + 1) = 14
+    collectives instead of 7, and an odd batch splits 2 + 1."""
+    from phyloformer_amd.engine import Engine
+    a = golden("configs.npz")["c2_idx"]                   # 3 x (20 x 200)
+    with Engine(weights("pf"), 0) as e:
+        ref = e.forward(a)
+        e.set_option("force_rccl", 1)
+        e.comm_init(e.unique_id(), 0, 1)
+        out, ncoll = {}, {}
+        for overlap in (0, 1):
+            e.set_option("overlap", overlap)
+            e.set_option("profile", 1)
+            e.profile_reset()
+            out[overlap] = e.forward_sharded(a, 0, 200, 200)
+            ncoll[overlap] = e.profile_get("allreduce")[0]
+            e.set_option("profile", 0)
+            again = e.forward_sharded(a, 0, 200, 200)     # un-profiled: the two streams really run concurrently
+            assert np.array_equal(again, out[overlap])
+        single = e.forward_sharded(a[:1], 0, 200, 200)    # one alignment: nothing to split
+        e.comm_destroy()
+    assert ncoll == {0: 7, 1: 14}
+    assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+    assert np.array_equal(single, ref[:1])

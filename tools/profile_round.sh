@@ -7,7 +7,7 @@ TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/stats_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/stats_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-power > $R/gpurun_out/stats_$TAG.log 2>&1
 cd $R
 bash tools/pmc.sh pmc_$TAG > gpurun_out/pmc_$TAG.log 2>&1
 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
