@@ -101,6 +101,11 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)
  *   "colstats_mfma" int 1 = column statistics with the MFMA formulation (k_colstats2) instead of the VALU
  *                      kernel (k_colstats): a measured alternative that is not faster; cross-check only
+ *   "main2"      int   1 = k_main2 (one wave per SIMD, two tiles in flight, hand-placed hidden loop) instead of
+ *                      the two-waves-per-SIMD k_main; same results bit for bit, measured 4 % slower (default 0)
+ *   "overlap"    int   0 = site-sharded forwards issue one collective per block for the whole batch instead of
+ *                      two half-batches on two streams
+ *   "reserve_cus" int  CUs the persistent kernels leave to the RCCL kernels while collectives run (default 8)
  *   "materialize_x0" int 1 = k_embed writes x0 = T[a_i] + T[a_j] to HBM and block 0 reads it (round-1 path);
  *                      default 0: block 0's kernels form it from the embedding table on the fly
  *   "embed_mfma" int   1 = compute block 0's row statistics with the MFMA kernel (k_main<FIRST>) instead of

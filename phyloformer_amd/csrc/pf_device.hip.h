@@ -228,7 +228,7 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
     r0 = g0 - __builtin_bit_cast(float, hb << 16);
     r1 = g1 - __builtin_bit_cast(float, hb & 0xffff0000u);
 #else
-    asm volatile(PF_DOT2C_PRE "v_dot2c_f32_bf16 %0, %2, %4\n\tv_dot2c_f32_bf16 %1, %3, %4" PF_DOT2C_POST
+    asm(PF_DOT2C_PRE "v_dot2c_f32_bf16 %0, %2, %4\n\tv_dot2c_f32_bf16 %1, %3, %4" PF_DOT2C_POST
                  : "+v"(r0), "+v"(r1) : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(hb));
 #endif
     const bf16x2 l2 = {(__bf16)r0, (__bf16)r1};
@@ -262,7 +262,9 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
         h[k] = __builtin_bit_cast(unsigned, h2);
     }
     float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7];
-    asm volatile(
+    // not volatile: a pure function of its operands, so the scheduler may interleave the splits of
+    // independent tiles (k_main2) instead of keeping every asm statement in program order
+    asm(
         "v_dot2c_f32_bf16 %0, %8, %10\n\tv_dot2c_f32_bf16 %1, %9, %10\n\t"
         "v_dot2c_f32_bf16 %2, %8, %11\n\tv_dot2c_f32_bf16 %3, %9, %11\n\t"
         "v_dot2c_f32_bf16 %4, %8, %12\n\tv_dot2c_f32_bf16 %5, %9, %12\n\t"

@@ -29,6 +29,7 @@
 
 #include "../../include/phyloformer_amd.h"
 #include "pf_device.hip.h"
+#include "pf_main2.hip.h"
 #include "pf_mha.hip.h"
 
 using namespace pfk;
@@ -237,6 +238,8 @@ struct pf_handle {
     bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
     bool colstats_mfma = false;   // option "colstats_mfma": k_colstats2 (MFMA formulation) instead of k_colstats
     bool materialize_x0 = false;  // option "materialize_x0": k_embed writes x0 and block 0 reads it (round-1 path)
+    bool main2 = false;           // option "main2": k_main2 (one wave per SIMD, two tiles, hand-placed hidden loop);
+                                  // bit-identical to k_main but 4 % slower, so off by default
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
     float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
     std::vector<BlockDev> blk;
@@ -622,7 +625,26 @@ int allreduce(pf_handle* h, float* buf, size_t count) {
 }
 
 template <int MODE>
+int launch_main2(pf_handle* h, const MainArgs& a, int kid) {
+    static bool attr_set[16] = {false};
+    if (!attr_set[h->device & 15]) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_main2<MODE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES));
+        attr_set[h->device & 15] = true;
+    }
+    const long ntasks = (long)a.B * a.P * ((a.Lloc + 31) / 32);      // tiles; a wave takes them two at a time
+    const int cus = std::max(1, h->prop.multiProcessorCount - (h->reducing ? h->reserve_cus : 0));
+    const int grid = (int)std::max<long>(1, std::min<long>(cus, (ntasks + 2 * MAIN2_WAVES - 1) / (2 * MAIN2_WAVES)));
+    ProfScope ps(h, kid);
+    hipLaunchKernelGGL(k_main2<MODE>, dim3(grid), dim3(MAIN2_THREADS), MAIN_LDS_BYTES, h->cur, a);
+    HIPCHK(h, hipGetLastError());
+    return PF_OK;
+}
+
+template <int MODE>
 int launch_main(pf_handle* h, const MainArgs& a, int kid) {
+    if (h->main2 && MODE != MODE_FIRST && !(h->ablate))
+        return launch_main2<MODE == MODE_FIRST ? MODE_MID : MODE>(h, a, kid);
     static bool attr_set[16] = {false};
     if (!attr_set[h->device & 15]) {
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_main<MODE>),
@@ -1084,6 +1106,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "embed_mfma") h->embed_mfma = value != 0;
     else if (k == "colstats_mfma") h->colstats_mfma = value != 0;
     else if (k == "materialize_x0") h->materialize_x0 = value != 0;
+    else if (k == "main2") h->main2 = value != 0;
     else if (k == "overlap") h->overlap = value != 0;
     else if (k == "reserve_cus") h->reserve_cus = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128));
     else if (k == "ablate") h->ablate = (int)value;

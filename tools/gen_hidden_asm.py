@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled FFN hidden loop of k_main (gfx950 inline asm).
 
-    python tools/gen_hidden_asm.py > phyloformer_amd/csrc/pf_hidden_asm.inc
+    python tools/gen_hidden_asm.py 6 base two > phyloformer_amd/csrc/pf_hidden_asm.inc     (product include)
+    python tools/gen_hidden_asm.py <fillers per MFMA gap> <mode> > /tmp/hid.inc                (tools/ffn3_bench.hip)
 
 The hidden loop (model.py:101-104, 64 -> 256 -> 64 with erf-GELU) is 72 % of k_main's MFMAs and half
 of its VALU work.  hipcc schedules it as MFMA clusters followed by VALU clusters and parks the GEMM1
@@ -371,7 +372,10 @@ def main():
         MODE = sys.argv[2]
     print("// GENERATED by tools/gen_hidden_asm.py - do not edit.  Hand-scheduled FFN hidden loop (gfx950).")
     print(f"// fillers per MFMA gap: {fill}")
-    for nm, gen in (("PF_HID2", gen_two_tile), ("PF_HID1", gen_one_tile)):
+    variants = (("PF_HID2", gen_two_tile), ("PF_HID1", gen_one_tile))
+    if len(sys.argv) > 3 and sys.argv[3] == "two":      # the product include only needs the two-tile stream
+        variants = variants[:1]
+    for nm, gen in variants:
         R, L = gen(fill)
         n_mfma = sum(1 for x in L if x.startswith("v_mfma"))
         print(f"// {nm}: {len(L)} instructions in the text, {n_mfma} MFMAs (static)")
