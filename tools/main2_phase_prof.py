@@ -8,6 +8,7 @@ from phyloformer_amd.engine import Engine
 from phyloformer_amd.weights import load_weights
 from phyloformer_amd.msa_sim import simulate_batch
 e = Engine(load_weights(os.path.join(REPO, "models/pf.ckpt")), 0)
+e.set_option("main2", 1)
 B = 16
 idx = np.ascontiguousarray(np.resize(simulate_batch(8, 60, 500, seed=3), (B, 60, 500)))
 e.forward(idx)
