@@ -851,10 +851,20 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     if (ok) {
         // partial statistics are summed in index order: the association is a function of the shape only
         const float* sp = a.srow + (size_t)pr * a.nparts * SROW;
+        // lanes 0..63 take S_kv[c], lanes 0..7 also S_q | S_k; four partials in flight per lane
+        const int c2 = 64 + (c & 7);
         float acc = 0.f, acc2 = 0.f;
-        for (int i = 0; i < a.nparts; ++i) {
+        int i = 0;
+        for (; i + 4 <= a.nparts; i += 4) {
+            const float* q0 = sp + i * SROW;
+            const float v0 = q0[c], v1 = q0[SROW + c], v2 = q0[2 * SROW + c], v3 = q0[3 * SROW + c];
+            const float w0 = q0[c2], w1 = q0[SROW + c2], w2 = q0[2 * SROW + c2], w3 = q0[3 * SROW + c2];
+            acc = (((acc + v0) + v1) + v2) + v3;
+            acc2 = (((acc2 + w0) + w1) + w2) + w3;
+        }
+        for (; i < a.nparts; ++i) {
             acc += sp[i * SROW + c];
-            if (c < 8) acc2 += sp[i * SROW + 64 + c];
+            acc2 += sp[i * SROW + c2];
         }
         st[sub][c] = acc;
         if (c < 8) st[sub][64 + c] = acc2;
@@ -948,6 +958,10 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     // two staging buffers of 16 pair matrices (5 x 64 floats each)
     __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
     __shared__ __attribute__((aligned(16))) float emb[EMBED ? 22 * 64 : 4];
+    // EMBED: the group's (i, j) sequence indices, so that the residue fetch of the next pair is one dependent
+    // load (idx byte) instead of two (pair table, then idx byte) - the second level did not fit one iteration
+    constexpr int PIJ_CAP = 640;
+    __shared__ int16_t pij[EMBED ? 2 * PIJ_CAP : 2];
     if (EMBED) {
         for (int i = threadIdx.x; i < 22 * 64 / 4; i += 256)
             reinterpret_cast<f32x4*>(emb)[i] = reinterpret_cast<const f32x4*>(a.table)[i];
@@ -987,13 +1001,21 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
     // the next pair's token row and q' are requested one iteration ahead (two ahead measured no better)
     f32x4 nx0, nx1, nqr;
     int nri = 0, nrj = 0;
+    const bool pij_lds = EMBED && (p1 - p0) <= PIJ_CAP;
+    if (pij_lds) {
+        for (int i = threadIdx.x; i < p1 - p0; i += 256) { pij[i] = a.pair_i[p0 + i]; pij[PIJ_CAP + i] = a.pair_j[p0 + i]; }
+        __syncthreads();
+    }
     auto fetch = [&](int p) {
         const int pc = min(p, a.P - 1);
         const size_t tk = ((size_t)b * a.P + pc) * a.Lloc + lcl;
         if (EMBED) {
             const uint8_t* ib = a.idx + (size_t)b * a.N * a.Lloc + lcl;
-            nri = ib[(size_t)a.pair_i[pc] * a.Lloc];
-            nrj = ib[(size_t)a.pair_j[pc] * a.Lloc];
+            const int pl = min(pc, p1 - 1) - p0;              // the prefetch past the group's end is never used
+            const int si = pij_lds ? (int)pij[pl] : (int)a.pair_i[pc];
+            const int sj = pij_lds ? (int)pij[PIJ_CAP + pl] : (int)a.pair_j[pc];
+            nri = ib[(size_t)si * a.Lloc];
+            nrj = ib[(size_t)sj * a.Lloc];
         } else {
             nx0 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
             nx1 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
