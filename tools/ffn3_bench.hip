@@ -1,6 +1,8 @@
 // Micro-benchmark + bit-exactness check of the hand-scheduled FFN hidden loop (tools/gen_hidden_asm.py).
-//   python tools/gen_hidden_asm.py 7 > /tmp/hid7.inc
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DPF_HID_INC='"/tmp/hid7.inc"' tools/ffn3_bench.hip -o tools/ffn3_bench
+//   python tools/gen_hidden_asm.py 6 base > /tmp/hid.inc       (both streams; modes: base nodot nosplit poly3 noexp movonly mfmaonly)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DPF_SH_CONST=0xbf800000u \
+//         -DPF_HID_INC='"/tmp/hid.inc"' tools/ffn3_bench.hip -o tools/ffn3_bench_base      (nodot: -DPF_SH_CONST=0xffff0000u)
+//   tools/run_ffn3.sh runs the prebuilt tools/ffn3_bench_<mode> binaries on the GPU box
 // Variants: plain C++ loop (the production body of round 1) with 1 or 2 waves per SIMD, the two-tile asm stream
 // (one wave per SIMD) and the one-tile software-pipelined asm stream (two waves per SIMD).
 #include <hip/hip_runtime.h>
