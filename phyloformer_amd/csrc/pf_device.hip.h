@@ -999,14 +999,17 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
         for (int i = 0; i < 8; ++i) z[hh][i] = 0.f;
 
     // the next pair's token row and q' are requested one iteration ahead (two ahead measured no better)
-    f32x4 nx0, nx1, nqr;
-    int nri = 0, nrj = 0;
+    // Two pairs are in flight per iteration: their chains (row mix -> LayerNorm -> projection -> butterfly ->
+    // activation) are independent, so the compiler interleaves them and the 0.7 us latency of one chain is
+    // shared by two pairs; Z~ is still updated pair by pair, in order (same bits as one pair at a time).
+    f32x4 nx0[2], nx1[2], nqr[2];
+    int nri[2] = {0, 0}, nrj[2] = {0, 0};
     const bool pij_lds = EMBED && (p1 - p0) <= PIJ_CAP;
     if (pij_lds) {
         for (int i = threadIdx.x; i < p1 - p0; i += 256) { pij[i] = a.pair_i[p0 + i]; pij[PIJ_CAP + i] = a.pair_j[p0 + i]; }
         __syncthreads();
     }
-    auto fetch = [&](int p) {
+    auto fetch = [&](int p, int u) {
         const int pc = min(p, a.P - 1);
         const size_t tk = ((size_t)b * a.P + pc) * a.Lloc + lcl;
         if (EMBED) {
@@ -1014,13 +1017,13 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
             const int pl = min(pc, p1 - 1) - p0;              // the prefetch past the group's end is never used
             const int si = pij_lds ? (int)pij[pl] : (int)a.pair_i[pc];
             const int sj = pij_lds ? (int)pij[PIJ_CAP + pl] : (int)a.pair_j[pc];
-            nri = ib[(size_t)si * a.Lloc];
-            nrj = ib[(size_t)sj * a.Lloc];
+            nri[u] = ib[(size_t)si * a.Lloc];
+            nrj[u] = ib[(size_t)sj * a.Lloc];
         } else {
-            nx0 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
-            nx1 = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
+            nx0[u] = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
+            nx1[u] = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
         }
-        nqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
+        nqr[u] = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
     };
     // The per-pair row-attention matrices are staged through LDS 16 pairs at a time (double-buffered):
     // read straight from L2, every 8-lane group of every wave would fetch them again - 10 KB of L1
@@ -1037,7 +1040,7 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
             __builtin_amdgcn_global_load_lds(src + min(i, n4 - 1), dst + (256 * k + 64 * wave) * 4, 16, 0, 0);
         }
     };
-    if (p0 < p1) { stage(p0, 0); fetch(p0); }
+    if (p0 < p1) { stage(p0, 0); fetch(p0, 0); fetch(p0 + 1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
@@ -1046,86 +1049,98 @@ __global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
       if (more) stage(pt + 16, buf ^ 1);                   // lands during this tile's compute
       const float* mt = mst + (size_t)buf * 16 * MROW;
       const int pe = min(pt + 16, p1);
-      for (int p = pt; p < pe; ++p) {
-        const size_t pr = (size_t)b * a.P + p;
-        const size_t tok = pr * a.Lloc + lcl;
-        f32x4 xv0, xv1;
-        const f32x4 qr = nqr;
-        if (EMBED) {
-            const float* ei = emb + nri * 64 + 8 * cl;
-            const float* ej = emb + nrj * 64 + 8 * cl;
-            xv0 = *reinterpret_cast<const f32x4*>(ei) + *reinterpret_cast<const f32x4*>(ej);
-            xv1 = *reinterpret_cast<const f32x4*>(ei + 4) + *reinterpret_cast<const f32x4*>(ej + 4);
-        } else {
-            xv0 = nx0; xv1 = nx1;
+      for (int p = pt; p < pe; p += 2) {
+        const bool two = p + 1 < pe;                       // wave-uniform (an odd group end leaves one pair)
+        f32x4 xv0[2], xv1[2], qr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            qr[u] = nqr[u];
+            if (EMBED) {
+                const float* ei = emb + nri[u] * 64 + 8 * cl;
+                const float* ej = emb + nrj[u] * 64 + 8 * cl;
+                xv0[u] = *reinterpret_cast<const f32x4*>(ei) + *reinterpret_cast<const f32x4*>(ej);
+                xv1[u] = *reinterpret_cast<const f32x4*>(ei + 4) + *reinterpret_cast<const f32x4*>(ej + 4);
+            } else {
+                xv0[u] = nx0[u]; xv1[u] = nx1[u];
+            }
         }
-        fetch(p + 1);
-        const float* m = mt + (p - pt) * MROW + 8 * cl;
-        f32x4 y0 = *reinterpret_cast<const f32x4*>(m + 4 * 64), y1 = *reinterpret_cast<const f32x4*>(m + 4 * 64 + 4);
+        fetch(p + 2, 0);
+        fetch(p + 3, 1);
+        float d[2][8], act[2];
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + hh * 64);
-            const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
+        for (int u = 0; u < 2; ++u) {
+            // (for a lone last pair the second chain recomputes the first pair's matrix row: finite, unused)
+            const float* m = mt + (two ? (p + u - pt) : (p - pt)) * MROW + 8 * cl;
+            f32x4 y0 = *reinterpret_cast<const f32x4*>(m + 4 * 64), y1 = *reinterpret_cast<const f32x4*>(m + 4 * 64 + 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { y0[i] = fmaf(qr[hh], m0[i], y0[i]); y1[i] = fmaf(qr[hh], m1[i], y1[i]); }
+            for (int hh = 0; hh < 4; ++hh) {
+                const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + hh * 64);
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { y0[i] = fmaf(qr[u][hh], m0[i], y0[i]); y1[i] = fmaf(qr[u][hh], m1[i], y1[i]); }
+            }
+            // x' = x + row attention of this block (bias row included)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { d[u][i] = xv0[u][i] + y0[i]; d[u][4 + i] = xv1[u][i] + y1[i]; }
+            float sm = ((d[u][0] + d[u][1]) + (d[u][2] + d[u][3])) + ((d[u][4] + d[u][5]) + (d[u][6] + d[u][7]));
+            sm += dpp_f<0x141>(sm);     // row_half_mirror: lane i <-> 7 - i
+            sm += dpp_f<0x1B>(sm);      // quad reverse
+            sm += dpp_f<0xB1>(sm);      // xor 1
+            const float mean = sm * (1.f / 64.f);
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { d[u][i] -= mean; v = fmaf(d[u][i], d[u][i], v); }
+            v += dpp_f<0x141>(v);
+            v += dpp_f<0x1B>(v);
+            v += dpp_f<0xB1>(v);
+            const float rstd = __builtin_amdgcn_rsqf(v * (1.f / 64.f) + LN_EPS);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[u][i] *= rstd;
+            // eight 64-long dot products: 8 channels per lane, then a transposing butterfly over the
+            // 8 lanes of the token (half mirror, quad reverse, xor 1)
+            float pv[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float acc = w[o][0] * d[u][0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) acc = fmaf(w[o][i], d[u][i], acc);
+                pv[o] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float send = up2 ? pv[i] : pv[i + 4], keep = up2 ? pv[i + 4] : pv[i];
+                pv[i] = keep + dpp_f<0x141>(send);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float send = up1 ? pv[i] : pv[i + 2], keep = up1 ? pv[i + 2] : pv[i];
+                pv[i] = keep + dpp_f<0x1B>(send);
+            }
+            {
+                const float send = up0 ? pv[0] : pv[1], keep = up0 ? pv[1] : pv[0];
+                pv[0] = keep + dpp_f<0xB1>(send);
+            }
+            act[u] = elu1_fast(pv[0] + bj) * vmask;   // q'[cl] or k'[cl - 4]
         }
-        // x' = x + row attention of this block (bias row included)
-        float d[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { d[i] = xv0[i] + y0[i]; d[4 + i] = xv1[i] + y1[i]; }
-        float sm = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
-        sm += dpp_f<0x141>(sm);     // row_half_mirror: lane i <-> 7 - i
-        sm += dpp_f<0x1B>(sm);      // quad reverse
-        sm += dpp_f<0xB1>(sm);      // xor 1
-        const float mean = sm * (1.f / 64.f);
-        float v = 0.f;
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const size_t tok = ((size_t)b * a.P + p + u) * a.Lloc + lcl;
+            s_acc += act[u];
+            if (lvalid && cl < 4) a.qcol[tok * 4 + cl] = act[u];
+            // k'[hh] sits in lane 4 + hh of this token's 8-lane group
+            const float k0 = swz<(4 << 5) | 0x18>(act[u]), k1 = swz<(5 << 5) | 0x18>(act[u]),
+                        k2 = swz<(6 << 5) | 0x18>(act[u]), k3 = swz<(7 << 5) | 0x18>(act[u]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { d[i] -= mean; v = fmaf(d[i], d[i], v); }
-        v += dpp_f<0x141>(v);
-        v += dpp_f<0x1B>(v);
-        v += dpp_f<0xB1>(v);
-        const float rstd = __builtin_amdgcn_rsqf(v * (1.f / 64.f) + LN_EPS);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] *= rstd;
-        // eight 64-long dot products: 8 channels per lane, then a transposing butterfly over the
-        // 8 lanes of the token (half mirror, quad reverse, xor 1)
-        float pv[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            float acc = w[o][0] * d[0];
-#pragma unroll
-            for (int i = 1; i < 8; ++i) acc = fmaf(w[o][i], d[i], acc);
-            pv[o] = acc;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float send = up2 ? pv[i] : pv[i + 4], keep = up2 ? pv[i + 4] : pv[i];
-            pv[i] = keep + dpp_f<0x141>(send);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float send = up1 ? pv[i] : pv[i + 2], keep = up1 ? pv[i + 2] : pv[i];
-            pv[i] = keep + dpp_f<0x1B>(send);
-        }
-        {
-            const float send = up0 ? pv[0] : pv[1], keep = up0 ? pv[1] : pv[0];
-            pv[0] = keep + dpp_f<0xB1>(send);
-        }
-        const float act = elu1_fast(pv[0] + bj) * vmask;   // q'[cl] or k'[cl - 4]
-        s_acc += act;
-        if (lvalid && cl < 4) a.qcol[tok * 4 + cl] = act;
-        // k'[hh] sits in lane 4 + hh of this token's 8-lane group
-        const float k0 = swz<(4 << 5) | 0x18>(act), k1 = swz<(5 << 5) | 0x18>(act),
-                    k2 = swz<(6 << 5) | 0x18>(act), k3 = swz<(7 << 5) | 0x18>(act);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            z[0][i] = fmaf(k0, d[i], z[0][i]);
-            z[1][i] = fmaf(k1, d[i], z[1][i]);
-            z[2][i] = fmaf(k2, d[i], z[2][i]);
-            z[3][i] = fmaf(k3, d[i], z[3][i]);
+            for (int i = 0; i < 8; ++i) {
+                z[0][i] = fmaf(k0, d[u][i], z[0][i]);
+                z[1][i] = fmaf(k1, d[u][i], z[1][i]);
+                z[2][i] = fmaf(k2, d[u][i], z[2][i]);
+                z[3][i] = fmaf(k3, d[u][i], z[3][i]);
+            }
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetch) have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetches) have landed
       __syncthreads();
     }
     // every wave owns its sites: one partial per (b, g, site), no cross-wave reduction
