@@ -384,8 +384,8 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 }
 
 // Work item = one tile of 32 consecutive sites of one (alignment, pair) row.  The B * P * ntiles tiles
-// are cut into one contiguous chunk per wave (a wave streams along rows, as HBM likes it); waves never
-// synchronise with each other after the LDS image is loaded.  Row statistics leave the kernel as one
+// are dealt to the waves in short runs of consecutive tiles, round-robin; waves never synchronise with
+// each other after the LDS image is loaded.  Row statistics leave the kernel as one
 // 72-float partial per TILE (summed in fixed order by k_rowfin / k_rowsum), never as per-wave running sums:
 // the result bits do not depend on how the tiles were dealt to waves, i.e. on batch size or grid, and a
 // lone small alignment still spreads over the whole chip (190 rows x 7 tiles of a 20 x 200 alignment are
@@ -432,12 +432,21 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     PF_OPAQUE(wop); PF_OPAQUE(wvp); PF_OPAQUE(qkp); PF_OPAQUE(lch);
 
     {
+        // Tiles are dealt in short RUNS of consecutive tiles, round-robin over the waves: at any moment the
+        // 2,048 waves work inside a window of nwaves * run tiles (a few hundred rows of one or two
+        // alignments), so ctx and the row-mix fragments stay hot in L2 - one contiguous chunk per wave had
+        // every wave in a different alignment and cost 0.7 GiB of extra L2 misses per launch (FETCH_SIZE 2.67
+        // -> 1.99 GiB, tools/fetch_ab.sh; the launch itself is 1 % slower this way, run lengths 2..16 alike)
+        // - while a wave still streams `run` consecutive 8 KB tiles and the load stays balanced to one run.
         const long nwaves = (long)gridDim.x * MAIN_WAVES;
-        const long chunk = (ntasks + nwaves - 1) / nwaves;
-        const long task0 = (long)(blockIdx.x * MAIN_WAVES + wave) * chunk;
-        const long task1 = min(ntasks, task0 + chunk);
-        int row = (int)(task0 / ntiles);            // b * P + p
-        int tile = (int)(task0 - (long)row * ntiles);
+#ifndef PF_RUN_MAX
+#define PF_RUN_MAX 8
+#endif
+        const long run = max(1L, min((long)PF_RUN_MAX, ntasks / (nwaves * 8)));
+        long run0 = (long)(blockIdx.x * MAIN_WAVES + wave) * run;      // first tile of this wave's current run
+        const long task0 = run0, task1 = ntasks;
+        int row = (int)(min(task0, ntasks - 1) / ntiles);            // b * P + p
+        int tile = (int)(min(task0, ntasks - 1) - (long)row * ntiles);
         int frag_row = -1;                          // the row whose row-mix fragments are in mfr
         bf16x8 mfr[4];
         // The next tile's residual rows and q' are requested when the FFN of the current tile starts
@@ -469,13 +478,22 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         };
         if (MODE != MODE_FIRST && task0 < task1) prefetch(row, tile);
 
-        for (long task = task0; task < task1; ++task) {
+        for (long task = task0; task < task1;) {
             const int b = row / a.P;
             const int p = row - b * a.P;
             const size_t row0 = (size_t)row * a.Lloc;  // first token of this pair row
-            // position of the tile that follows in this wave's chunk
-            const int ntile = (tile + 1 < ntiles) ? tile + 1 : 0;
-            const int nrow = (tile + 1 < ntiles) ? row : row + 1;
+            // the tile that follows: the next one of this run, or the first one of the wave's next run
+            long ntask = task + 1;
+            int ntile = (tile + 1 < ntiles) ? tile + 1 : 0;
+            int nrow = (tile + 1 < ntiles) ? row : row + 1;
+            if (ntask == run0 + run) {
+                run0 += nwaves * run;
+                ntask = run0;
+                if (ntask < task1) {
+                    nrow = (int)(ntask / ntiles);
+                    ntile = (int)(ntask - (long)nrow * ntiles);
+                }
+            }
             int ai = 0, aj = 0;
             if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
             if (MODE != MODE_FIRST && row != frag_row) {
@@ -588,7 +606,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     load_acc_bias(oa[1], lch + CONST_B2 + 32);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
-                    if (task + 1 < task1) prefetch(nrow, ntile);
+                    if (ntask < task1) prefetch(nrow, ntile);
                     PF_TICK(2);
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
@@ -651,7 +669,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         xo[2 * g] = u;
                     }
                 }
-                if (a.ablate & 32) { tile = ntile; row = nrow; continue; }   // perf experiment: copy-only
+                if (a.ablate & 32) { tile = ntile; row = nrow; task = ntask; continue; }   // perf experiment: copy-only
                 f32x16 va[3];
                 {
                     float xn[32];
@@ -736,6 +754,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             PF_TICK(4);
             tile = ntile;
             row = nrow;
+            task = ntask;
         }
     }
     if (a.prof && lane == 0) {
