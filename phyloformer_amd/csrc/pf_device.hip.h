@@ -611,6 +611,85 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
                     if (ntask < task1) prefetch(nrow, ntile);
                     PF_TICK(2);
+#ifdef PF_LOOP_PIPE
+                    // Software pipeline over the hidden tiles with hand-placed program order: every group is one
+                    // MFMA - alternately GEMM1 of tile T+1 and GEMM2 of tile T-1, so consecutive MFMAs never
+                    // share an accumulator - followed by the GELU chain of ONE hidden value of tile T (or the
+                    // split of one value pair), closed by sched_barrier(0) so that hipcc keeps the order.
+                    {
+                        auto step = [&](f32x16& hn, const f32x16& hc, unsigned (&gch)[8], unsigned (&gcl)[8],
+                                        const unsigned (&gph)[8], const unsigned (&gpl)[8], lds_frag_t f1n, lds_f32_t bpn,
+                                        lds_frag_t f2p, const bool g1, const bool g2) {
+                            if (g1) load_acc_bias(hn, bpn);
+                            float gv[16];
+                            bf16x8 ah, al, wh, wl;
+#pragma unroll
+                            for (int i = 0; i < 24; ++i) {
+                                const int k = i >> 1;                    // MFMA index inside its GEMM (0..11)
+                                const int s4 = k / 3, pass = k % 3;
+                                if ((i & 1) == 0) {
+                                    if (g1) {
+                                        if (pass == 0) { ah = f1n[s4 * 128]; al = f1n[s4 * 128 + 64]; }
+                                        hn = PF_MFMA(pass == 0 ? al : ah, pass == 1 ? xb_lo[s4] : xb_hi[s4], hn);
+                                    }
+                                } else if (g2) {
+                                    const int u = s4 >> 1, To = s4 & 1;
+                                    if (pass == 0) { wh = f2p[(To * 32 + u * 2) * 64]; wl = f2p[(To * 32 + u * 2) * 64 + 64]; }
+                                    bf16x8 ghi, glo;
+                                    {
+                                        u32x4 qh = {gph[4 * u], gph[4 * u + 1], gph[4 * u + 2], gph[4 * u + 3]};
+                                        u32x4 ql = {gpl[4 * u], gpl[4 * u + 1], gpl[4 * u + 2], gpl[4 * u + 3]};
+                                        ghi = __builtin_bit_cast(bf16x8, qh);
+                                        glo = __builtin_bit_cast(bf16x8, ql);
+                                    }
+                                    oa[To] = PF_MFMA(pass == 0 ? wl : wh, pass == 1 ? glo : ghi, oa[To]);
+                                }
+                                if (i < 16) gv[i] = gelu_scaled(hc[i]);
+                                else split_pair(gv[2 * (i - 16)], gv[2 * (i - 16) + 1], gch[i - 16], gcl[i - 16]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        };
+                        f32x16 hA, hB;
+                        unsigned gAh[8], gAl[8], gBh[8], gBl[8];
+                        {   // prologue: GEMM1 of hidden tile 0
+                            lds_frag_t f1 = w1p; lds_f32_t bp = lch + CONST_B1;
+                            PF_OPAQUE(f1); PF_OPAQUE(bp);
+                            load_acc_bias(hA, bp);
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                const bf16x8 fh = f1[s4 * 128], fl = f1[s4 * 128 + 64];
+                                mfma3(hA, fh, fl, xb_hi[s4], xb_lo[s4]);
+                            }
+                        }
+                        {   // T = 0: GEMM1(1) beside gelu(0)
+                            lds_frag_t f1 = w1p + 512; lds_f32_t bp = lch + CONST_B1 + 32;
+                            PF_OPAQUE(f1); PF_OPAQUE(bp);
+                            step(hB, hA, gAh, gAl, gAh, gAl, f1, bp, f1, true, false);
+                        }
+#pragma unroll 1
+                        for (int j = 0; j < 3; ++j) {
+                            lds_frag_t f1 = w1p + (2 * j + 2) * 512;      // W1 of tile 2j+2 (and 2j+3 at +512)
+                            lds_frag_t f2 = w2p + (2 * j) * 256;          // W2 of tile 2j (and 2j+1 at +256)
+                            lds_f32_t bp = lch + CONST_B1 + 32 * (2 * j + 2);
+                            PF_OPAQUE(f1); PF_OPAQUE(f2); PF_OPAQUE(bp);
+                            step(hA, hB, gBh, gBl, gAh, gAl, f1, bp, f2, true, true);                   // T = 2j+1
+                            step(hB, hA, gAh, gAl, gBh, gBl, f1 + 512, bp + 32, f2 + 256, true, true);   // T = 2j+2
+                        }
+                        {   // T = 7: GEMM2(6) beside gelu(7); then GEMM2(7)
+                            lds_frag_t f2 = w2p + 6 * 256;
+                            PF_OPAQUE(f2);
+                            step(hA, hB, gBh, gBl, gAh, gAl, f2, lch, f2, false, true);
+#pragma unroll
+                            for (int st = 0; st < 4; ++st) {
+                                const int u = st >> 1, To = st & 1;
+                                const bf16x8 fh = f2[256 + (To * 32 + u * 2) * 64], fl = f2[256 + (To * 32 + u * 2) * 64 + 64];
+                                u32x4 qh = {gBh[4 * u], gBh[4 * u + 1], gBh[4 * u + 2], gBh[4 * u + 3]};
+                                u32x4 ql = {gBl[4 * u], gBl[4 * u + 1], gBl[4 * u + 2], gBl[4 * u + 3]};
+                                mfma3(oa[To], fh, fl, __builtin_bit_cast(bf16x8, qh), __builtin_bit_cast(bf16x8, ql));
+                            }
+                        }
+                    }
+#else
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
                         f32x16 ha;
@@ -647,6 +726,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                             fh = nh; fl = nl;
                         }
                     }
+#endif
                     PF_TICK(3);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) x[j] = oa[j >> 4][j & 15];
