@@ -291,22 +291,39 @@ __device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8&
 
 #define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-// acc += (a_hi + a_lo) * (b_hi + b_lo) without the lo*lo term
+// acc += (a_hi + a_lo) * (b_hi + b_lo) without the lo*lo term.
+// Pass order: consecutive MFMAs share one operand - (hi,lo) (hi,hi) (lo,hi): A changes once, B changes once -
+// and `flip` reverses it, so that two back-to-back calls with the same B operand (two output tiles of one K step)
+// also share it across the seam: ... (lo,hi) | (lo',hi) (hi',hi) (hi',lo).  Fewer operand switches between
+// consecutive MFMAs measurably lower the power the matrix pipe draws: -1.0 % launch time against the
+// (lo,hi) (hi,lo) (hi,hi) order of round 1 (A/B in one GPU call, tools/flag_compare.py).
 __device__ __forceinline__ void mfma3(f32x16& acc, const bf16x8& a_hi, const bf16x8& a_lo,
-                                      const bf16x8& b_hi, const bf16x8& b_lo) {
-    acc = PF_MFMA(a_lo, b_hi, acc);
-    acc = PF_MFMA(a_hi, b_lo, acc);
-    acc = PF_MFMA(a_hi, b_hi, acc);
+                                      const bf16x8& b_hi, const bf16x8& b_lo, const bool flip = false) {
+    if (!flip) {
+        acc = PF_MFMA(a_hi, b_lo, acc);
+        acc = PF_MFMA(a_hi, b_hi, acc);
+        acc = PF_MFMA(a_lo, b_hi, acc);
+    } else {
+        acc = PF_MFMA(a_lo, b_hi, acc);
+        acc = PF_MFMA(a_hi, b_hi, acc);
+        acc = PF_MFMA(a_hi, b_lo, acc);
+    }
 }
 
 // first product of a chain: C is the inline constant 0 of the MFMA encoding, so the accumulator needs no
 // sixteen v_mov to be cleared
 __device__ __forceinline__ void mfma3_zero(f32x16& acc, const bf16x8& a_hi, const bf16x8& a_lo,
-                                           const bf16x8& b_hi, const bf16x8& b_lo) {
+                                           const bf16x8& b_hi, const bf16x8& b_lo, const bool flip = false) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    acc = PF_MFMA(a_lo, b_hi, z);
-    acc = PF_MFMA(a_hi, b_lo, acc);
-    acc = PF_MFMA(a_hi, b_hi, acc);
+    if (!flip) {
+        acc = PF_MFMA(a_hi, b_lo, z);
+        acc = PF_MFMA(a_hi, b_hi, acc);
+        acc = PF_MFMA(a_lo, b_hi, acc);
+    } else {
+        acc = PF_MFMA(a_lo, b_hi, z);
+        acc = PF_MFMA(a_hi, b_hi, acc);
+        acc = PF_MFMA(a_hi, b_lo, acc);
+    }
 }
 
 // LayerNorm without affine over the 64 channels of a token held by lanes (t,0) and (t,1)
@@ -564,7 +581,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do, so
                         // they hold their partner's fragment instead of a masked load
 #pragma unroll
-                        for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo);
+                        for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo, To == 1);
                     }
                     // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
                     {
@@ -584,7 +601,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                             for (int To = 0; To < 2; ++To) {
                                 lds_frag_t f = wop + ((To * 4 + s) * 2) * 64;
                                 const bf16x8 a_hi = f[0], a_lo = f[64];
-                                mfma3(ya[To], a_hi, a_lo, ob_hi, ob_lo);
+                                mfma3(ya[To], a_hi, a_lo, ob_hi, ob_lo, To == 1);
                             }
                         }
                     }
@@ -630,7 +647,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                                 if ((i & 1) == 0) {
                                     if (g1) {
                                         if (pass == 0) { ah = f1n[s4 * 128]; al = f1n[s4 * 128 + 64]; }
-                                        hn = PF_MFMA(pass == 0 ? al : ah, pass == 1 ? xb_lo[s4] : xb_hi[s4], hn);
+                                        hn = PF_MFMA(pass == 2 ? al : ah, pass == 0 ? xb_lo[s4] : xb_hi[s4], hn);
                                     }
                                 } else if (g2) {
                                     const int u = s4 >> 1, To = s4 & 1;
@@ -642,7 +659,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                                         ghi = __builtin_bit_cast(bf16x8, qh);
                                         glo = __builtin_bit_cast(bf16x8, ql);
                                     }
-                                    oa[To] = PF_MFMA(pass == 0 ? wl : wh, pass == 1 ? glo : ghi, oa[To]);
+                                    // (hi,lo) (hi,hi) (lo,hi) for To = 0, reversed for To = 1: same order as mfma3()
+                                    const int ps = To ? 2 - pass : pass;
+                                    oa[To] = PF_MFMA(ps == 2 ? wl : wh, ps == 0 ? glo : ghi, oa[To]);
                                 }
                                 if (i < 16) gv[i] = gelu_scaled(hc[i]);
                                 else split_pair(gv[2 * (i - 16)], gv[2 * (i - 16) + 1], gch[i - 16], gcl[i - 16]);
@@ -685,7 +704,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                                 const bf16x8 fh = f2[256 + (To * 32 + u * 2) * 64], fl = f2[256 + (To * 32 + u * 2) * 64 + 64];
                                 u32x4 qh = {gBh[4 * u], gBh[4 * u + 1], gBh[4 * u + 2], gBh[4 * u + 3]};
                                 u32x4 ql = {gBl[4 * u], gBl[4 * u + 1], gBl[4 * u + 2], gBl[4 * u + 3]};
-                                mfma3(oa[To], fh, fl, __builtin_bit_cast(bf16x8, qh), __builtin_bit_cast(bf16x8, ql));
+                                mfma3(oa[To], fh, fl, __builtin_bit_cast(bf16x8, qh), __builtin_bit_cast(bf16x8, ql), To == 1);
                             }
                         }
                     }
@@ -722,7 +741,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                                 nh = f2[(nTo * 32 + nu * 2) * 64];
                                 nl = f2[(nTo * 32 + nu * 2) * 64 + 64];
                             }
-                            mfma3(oa[To], fh, fl, g_hi[u], g_lo[u]);
+                            mfma3(oa[To], fh, fl, g_hi[u], g_lo[u], To == 1);
                             fh = nh; fl = nl;
                         }
                     }
@@ -774,8 +793,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 #pragma unroll
                         for (int T = 0; T < 2; ++T) {
                             const bf16x8 f_hi = wvp[(T * 4 + s) * 64];
-                            if (s == 0) mfma3_zero(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
-                            else mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s]);
+                            if (s == 0) mfma3_zero(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s], T == 1);
+                            else mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s], T == 1);
                         }
                 }
 #pragma unroll
@@ -1408,7 +1427,7 @@ __global__ void __launch_bounds__(CS2_THREADS, 2) k_colstats2(ColStats2Args a) {
             bf16x8 qb_hi, qb_lo;
             split8(v, qb_hi, qb_lo);
 #pragma unroll
-            for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo);
+            for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo, To == 1);
             stage_frags(pn);                                    // mfr is in registers: its LDS slot is free
         }
         PF_TICK(1);

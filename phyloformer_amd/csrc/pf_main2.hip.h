@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(MAIN2_THREADS, 1) k_main2(MainArgs a) {
                 bf16x8 qb_hi, qb_lo;
                 split8(v, qb_hi, qb_lo);
 #pragma unroll
-                for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[u][To * 2], mfr[u][To * 2 + 1], qb_hi, qb_lo);
+                for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[u][To * 2], mfr[u][To * 2 + 1], qb_hi, qb_lo, To == 1);
             }
             {
                 const f32x4 qc = pqc[u];
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(MAIN2_THREADS, 1) k_main2(MainArgs a) {
                     for (int To = 0; To < 2; ++To) {
                         lds_frag_t f = wop + ((To * 4 + s) * 2) * 64;
                         const bf16x8 a_hi = f[0], a_lo = f[64];
-                        mfma3(ya[To], a_hi, a_lo, ob_hi, ob_lo);
+                        mfma3(ya[To], a_hi, a_lo, ob_hi, ob_lo, To == 1);
                     }
                 }
             }
@@ -306,8 +306,8 @@ __global__ void __launch_bounds__(MAIN2_THREADS, 1) k_main2(MainArgs a) {
 #pragma unroll
                         for (int Tt = 0; Tt < 2; ++Tt) {
                             const bf16x8 f_hi = wvp[(Tt * 4 + s) * 64];
-                            if (s == 0) mfma3_zero(va[Tt], f_hi, wl[Tt * 4 + s], nb_hi[s], nb_lo[s]);
-                            else mfma3(va[Tt], f_hi, wl[Tt * 4 + s], nb_hi[s], nb_lo[s]);
+                            if (s == 0) mfma3_zero(va[Tt], f_hi, wl[Tt * 4 + s], nb_hi[s], nb_lo[s], Tt == 1);
+                            else mfma3(va[Tt], f_hi, wl[Tt * 4 + s], nb_hi[s], nb_lo[s], Tt == 1);
                         }
                 }
 #pragma unroll

@@ -228,18 +228,22 @@ def half_step(R, X, Y, g2, g1, gelu, w1_off, w2_off, b_off, load_bias_next, firs
         hacc = R.vt(ha, 16)
         csrc = R.vt(R.bias, 16) if i == 0 else hacc
         mf = []
+        # pass order as mfma3() in pf_device.hip.h: (hi,lo) (hi,hi) (lo,hi); GEMM2's second output tile of a K
+        # step reversed, so that consecutive MFMAs on one accumulator chain share an operand (bit-identical sums)
         g1m = [
-            f"v_mfma_f32_32x32x16_bf16 {hacc}, {al}, {R.vt(xh + 4 * i, 4)}, {csrc}",
-            f"v_mfma_f32_32x32x16_bf16 {hacc}, {ah}, {R.vt(xl + 4 * i, 4)}, {hacc}",
+            f"v_mfma_f32_32x32x16_bf16 {hacc}, {ah}, {R.vt(xl + 4 * i, 4)}, {csrc}",
             f"v_mfma_f32_32x32x16_bf16 {hacc}, {ah}, {R.vt(xh + 4 * i, 4)}, {hacc}",
+            f"v_mfma_f32_32x32x16_bf16 {hacc}, {al}, {R.vt(xh + 4 * i, 4)}, {hacc}",
         ]
         oacc = R.at(oa1 if To else oa0, 16)
         ghi, glo = R.vt(gx + 4 * u, 4), R.vt(gx + 8 + 4 * u, 4)
         g2m = [
-            f"v_mfma_f32_32x32x16_bf16 {oacc}, {wl}, {ghi}, {oacc}",
             f"v_mfma_f32_32x32x16_bf16 {oacc}, {wh}, {glo}, {oacc}",
             f"v_mfma_f32_32x32x16_bf16 {oacc}, {wh}, {ghi}, {oacc}",
+            f"v_mfma_f32_32x32x16_bf16 {oacc}, {wl}, {ghi}, {oacc}",
         ]
+        if To:
+            g2m.reverse()
         for k in range(3):
             if g1:
                 mf.append(g1m[k])
