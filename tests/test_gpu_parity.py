@@ -72,8 +72,9 @@ def test_tiny_taps_localise_every_kernel(engines, weights, golden):
     e = engines("pf")
     e.set_option("debug_keep", 1)
     try:
-        # per-buffer bounds are loose enough for fp32 re-association on this adversarial input
-        # and tight enough that any layout / indexing bug (O(1) errors) trips them
+        # per-buffer bounds (relative to the largest reference entry): 3-4 x the measured errors on this
+        # adversarial input (worst: srow 2.4e-5, mrow 2.5e-5, ctx 8.6e-5, x 3.2e-5 in block 5, error table in
+        # DESIGN.md section 5) and far below what any layout / indexing bug (O(1) errors) produces
         d = e.forward(g["idx"])
         P, L = 10, 16
         x0 = e.debug_read("x0").reshape(P, L, 64)
@@ -82,16 +83,26 @@ def test_tiny_taps_localise_every_kernel(engines, weights, golden):
         for k in range(6):
             srow = e.debug_read(f"srow{k}").reshape(P, 72)
             want, _q = devmath.expected_srow(w, k, x_in)
-            assert np.abs(srow - want).max() <= 2e-4 * np.abs(want).max(), f"srow{k}"
+            tap_rel = {}
+
+            def close(name, got, wnt, rel):
+                # measured margins go into the error table (relative to the largest reference entry)
+                tap_rel[name] = float(np.abs(got - wnt).max() / np.abs(wnt).max())
+                assert tap_rel[name] <= rel, (name, tap_rel[name])
+
+            close(f"srow{k}", srow, want, 1e-4)
             mrow = e.debug_read(f"mrow{k}").reshape(P, 5, 64)
             wantm = devmath.expected_mrow(w, k, want, L)
-            assert np.abs(mrow - wantm).max() <= 5e-4 * np.abs(wantm).max(), f"mrow{k}"
+            close(f"mrow{k}", mrow, wantm, 1e-4)
             ctx = e.debug_read(f"ctx{k}").reshape(L, 64)
             wantc, _qc = devmath.expected_ctx(w, k, g[f"block{k}.row"])
-            assert np.abs(ctx - wantc).max() <= 5e-4 * np.abs(wantc).max(), f"ctx{k}"
+            close(f"ctx{k}", ctx, wantc, 3e-4)
             xk = e.debug_read(f"x{k + 1}").reshape(P, L, 64)
             ref = g[f"block{k}.ffn"]
-            assert np.abs(xk - ref).max() <= 2e-4 * np.abs(ref).max(), f"x{k + 1}"
+            close(f"x{k + 1}", xk, ref, 1e-4)
+            _ERRORS[f"tiny_taps block {k}: relative error of srow / mrow / ctx / x"] = {
+                "max_abs_err": max(tap_rel.values()), "max_abs_ref": None,
+                "detail": {n: round(v, 9) for n, v in tap_rel.items()}}
             x_in = ref
         # uniform-random residues incl. X and gaps drive |x| to ~130 and distances to ~12; the
         # reference's own fp32-vs-fp64 gap is 1e-5 here, so the bound is relative (1e-4 of 12)
