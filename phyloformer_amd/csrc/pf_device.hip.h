@@ -1077,7 +1077,10 @@ constexpr int CPART = 4 * 64 + 8;
 // LayerNorm -> q', k' -> Z~ += k' x~.  Eight lanes per token: three steps per cross-lane reduction and,
 // after the transposing butterfly, exactly one projection per lane - 24 VALU instructions per token.
 template <bool EMBED>
-__global__ void __launch_bounds__(256) k_colstats(ColStatsArgs a) {
+#ifndef PF_CS_WAVES
+#define PF_CS_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     // two staging buffers of 16 pair matrices (5 x 64 floats each)
     __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
     __shared__ __attribute__((aligned(16))) float emb[EMBED ? 22 * 64 : 4];
