@@ -101,6 +101,8 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)
  *   "colstats_mfma" int 1 = column statistics with the MFMA formulation (k_colstats2) instead of the VALU
  *                      kernel (k_colstats): a measured alternative that is not faster; cross-check only
+ *   "colstats_fine" int k_colstats blocks per pair group (0), per run of a group (1) or chosen from the batch
+ *                      size (-1, default): the same summation tree either way, so the same bits; tests/tools
  *   "main2"      int   1 = k_main2 (one wave per SIMD, two tiles in flight, hand-placed hidden loop) instead of
  *                      the two-waves-per-SIMD k_main; same results bit for bit, measured 4 % slower (default 0)
  *   "overlap"    int   0 = site-sharded forwards issue one collective per block for the whole batch instead of

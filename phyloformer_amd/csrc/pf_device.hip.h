@@ -1061,6 +1061,12 @@ struct ColStatsArgs {
     const float* wqk;    // [8][64] folded col q (rows 0-3) and k (rows 4-7)
     const float* bqk;    // [8]
     int B, P, Lloc, G, nchunks;
+    // Fixed two-level association of the sum over pairs: every group is cut into runs of `sub` pairs (a multiple
+    // of 16; S = runs per group); a run is summed pair by pair from zero, a group is the in-order sum of its
+    // runs, the total (k_colfin) the in-order sum of the groups.  fine = 0: one block walks a whole group and
+    // folds run after run in registers (part[b][g][l]); fine = 1: one block per run (part[b][g][s][l]) and
+    // k_colfin folds - the same tree, so the same bits, whichever way the host picks for the batch at hand.
+    int sub, S, fine;
     // block 0 only (EMBED): x0[p = (i, j)][l] = table[idx[i][l]] + table[idx[j][l]]
     const float* table;      // [22][64]
     const uint8_t* idx;      // [B][N][Lloc]
@@ -1110,19 +1116,33 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     const float bj = a.bqk[cl];
     const bool up2 = (cl & 4) != 0, up1 = (cl & 2) != 0, up0 = (cl & 1) != 0;
     int bid = blockIdx.x;
+    int run = 0;
+    if (a.fine) { run = bid % a.S; bid /= a.S; }
     const int g = bid % a.G; bid /= a.G;
     const int chunk = bid % a.nchunks;
     const int b = bid / a.nchunks;
     const int l = chunk * 32 + wave * 8 + ts;
     const bool lvalid = l < a.Lloc;
     const int lcl = lvalid ? l : a.Lloc - 1;
-    const int p0 = g * per, p1 = min(a.P, p0 + per);
+    const int gp0 = g * per, gp1 = min(a.P, gp0 + per);
+    const int p0 = a.fine ? gp0 + run * a.sub : gp0, p1 = a.fine ? min(gp1, p0 + a.sub) : gp1;
+    if (p0 >= p1) return;       // a run past the end of the last group (k_colfin does not read its slot)
     const float vmask = lvalid ? 1.f : 0.f;
-    float z[4][8], s_acc = 0.f;
+    float z[4][8], s_acc = 0.f, zt[4][8], s_tot = 0.f;
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) z[hh][i] = 0.f;
+        for (int i = 0; i < 8; ++i) { z[hh][i] = 0.f; zt[hh][i] = 0.f; }
+    auto fold = [&]() {         // group += run; run = 0
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                zt[hh][i] += z[hh][i];
+                z[hh][i] = 0.f;
+            }
+        s_tot += s_acc; s_acc = 0.f;
+    };
 
     // the next pair's token row and q' are requested one iteration ahead (two ahead measured no better)
     // Two pairs are in flight per iteration: their chains (row mix -> LayerNorm -> projection -> butterfly ->
@@ -1138,18 +1158,29 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     auto fetch = [&](int p, int u) {
         const int pc = min(p, a.P - 1);
         const size_t tk = ((size_t)b * a.P + pc) * a.Lloc + lcl;
-        if (EMBED) {
-            const uint8_t* ib = a.idx + (size_t)b * a.N * a.Lloc + lcl;
-            const int pl = min(pc, p1 - 1) - p0;              // the prefetch past the group's end is never used
-            const int si = pij_lds ? (int)pij[pl] : (int)a.pair_i[pc];
-            const int sj = pij_lds ? (int)pij[PIJ_CAP + pl] : (int)a.pair_j[pc];
-            nri[u] = ib[(size_t)si * a.Lloc];
-            nrj[u] = ib[(size_t)sj * a.Lloc];
-        } else {
+        if (!EMBED) {
             nx0[u] = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl);
             nx1[u] = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
         }
         nqr[u] = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
+    };
+    // EMBED: x0 of a pair is two table rows; its residues are requested two iterations ahead and the rows read
+    // from LDS one iteration ahead (residue load -> LDS read -> use is a dependent chain: inside one iteration
+    // it sat on the critical path whenever the compiler's schedule changed)
+    auto fetch_idx = [&](int p, int u) {
+        const int pc = min(p, a.P - 1);
+        const uint8_t* ib = a.idx + (size_t)b * a.N * a.Lloc + lcl;
+        const int pl = min(pc, p1 - 1) - p0;                  // the prefetch past the group's end is never used
+        const int si = pij_lds ? (int)pij[pl] : (int)a.pair_i[pc];
+        const int sj = pij_lds ? (int)pij[PIJ_CAP + pl] : (int)a.pair_j[pc];
+        nri[u] = ib[(size_t)si * a.Lloc];
+        nrj[u] = ib[(size_t)sj * a.Lloc];
+    };
+    auto lookup = [&](int u) {
+        const float* ei = emb + nri[u] * 64 + 8 * cl;
+        const float* ej = emb + nrj[u] * 64 + 8 * cl;
+        nx0[u] = *reinterpret_cast<const f32x4*>(ei) + *reinterpret_cast<const f32x4*>(ej);
+        nx1[u] = *reinterpret_cast<const f32x4*>(ei + 4) + *reinterpret_cast<const f32x4*>(ej + 4);
     };
     // The per-pair row-attention matrices are staged through LDS 16 pairs at a time (double-buffered):
     // read straight from L2, every 8-lane group of every wave would fetch them again - 10 KB of L1
@@ -1166,9 +1197,11 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
             __builtin_amdgcn_global_load_lds(src + min(i, n4 - 1), dst + (256 * k + 64 * wave) * 4, 16, 0, 0);
         }
     };
-    if (p0 < p1) { stage(p0, 0); fetch(p0, 0); fetch(p0 + 1, 1); }
+    stage(p0, 0); fetch(p0, 0); fetch(p0 + 1, 1);
+    if (EMBED) { fetch_idx(p0, 0); fetch_idx(p0 + 1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (EMBED) { lookup(0); lookup(1); fetch_idx(p0 + 2, 0); fetch_idx(p0 + 3, 1); }
     int buf = 0;
     for (int pt = p0; pt < p1; pt += 16, buf ^= 1) {
       const bool more = pt + 16 < p1;
@@ -1179,17 +1212,8 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
         const bool two = p + 1 < pe;                       // wave-uniform (an odd group end leaves one pair)
         f32x4 xv0[2], xv1[2], qr[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            qr[u] = nqr[u];
-            if (EMBED) {
-                const float* ei = emb + nri[u] * 64 + 8 * cl;
-                const float* ej = emb + nrj[u] * 64 + 8 * cl;
-                xv0[u] = *reinterpret_cast<const f32x4*>(ei) + *reinterpret_cast<const f32x4*>(ej);
-                xv1[u] = *reinterpret_cast<const f32x4*>(ei + 4) + *reinterpret_cast<const f32x4*>(ej + 4);
-            } else {
-                xv0[u] = nx0[u]; xv1[u] = nx1[u];
-            }
-        }
+        for (int u = 0; u < 2; ++u) { qr[u] = nqr[u]; xv0[u] = nx0[u]; xv1[u] = nx1[u]; }
+        if (EMBED) { lookup(0); lookup(1); fetch_idx(p + 4, 0); fetch_idx(p + 5, 1); }
         fetch(p + 2, 0);
         fetch(p + 3, 1);
         float d[2][8], act[2];
@@ -1268,18 +1292,21 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetches) have landed
       __syncthreads();
+      if (more && (pt + 16 - p0) % a.sub == 0) fold();    // a run boundary inside the group (fine = 0 only)
     }
-    // every wave owns its sites: one partial per (b, g, site), no cross-wave reduction
+    fold();
+    // every wave owns its sites: one partial per (b, g[, run], site), no cross-wave reduction
     if (lvalid) {
-        float* out = a.part + (((size_t)b * a.G + g) * a.Lloc + l) * CPART;
+        const size_t slot = a.fine ? ((size_t)b * a.G + g) * a.S + run : (size_t)b * a.G + g;
+        float* out = a.part + (slot * a.Lloc + l) * CPART;
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                f32x4 u = {z[hh][4 * q], z[hh][4 * q + 1], z[hh][4 * q + 2], z[hh][4 * q + 3]};
+                f32x4 u = {zt[hh][4 * q], zt[hh][4 * q + 1], zt[hh][4 * q + 2], zt[hh][4 * q + 3]};
                 *reinterpret_cast<f32x4*>(out + hh * 64 + 8 * cl + 4 * q) = u;
             }
-        out[256 + cl] = s_acc;      // S_q[0..3] | S_k[0..3]
+        out[256 + cl] = s_tot;      // S_q[0..3] | S_k[0..3]
     }
 }
 
@@ -1508,24 +1535,45 @@ struct ColFinArgs {
     const float* bv;     // [64] folded col v bias
     int B, Lloc, G;
     float P;
+    int npairs, sub, S, fine;   // the association tree of ColStatsArgs (fine = 1: part[b][g][s][l], folded here)
 };
 
-__global__ void __launch_bounds__(256) k_colfin(ColFinArgs a) {
+constexpr int COLFIN_THREADS = 320;      // >= CPART: one value per thread
+__global__ void __launch_bounds__(COLFIN_THREADS) k_colfin(ColFinArgs a) {
     __shared__ float zs[CPART];
     const int site = blockIdx.x;  // b * Lloc + l
     const int b = site / a.Lloc, l = site - b * a.Lloc;
-    for (int i = threadIdx.x; i < CPART; i += 256) {
+    const size_t gs = (size_t)a.Lloc * CPART;
+    const int per = (a.npairs + a.G - 1) / a.G;
+    const int i = threadIdx.x;
+    if (i < CPART) {
         // partials are summed in group order (fixed association); four loads in flight per thread
-        const float* pp = a.part + ((size_t)b * a.G * a.Lloc + l) * CPART + i;
-        const size_t gs = (size_t)a.Lloc * CPART;
         float acc = 0.f;
-        int g = 0;
-        for (; g + 4 <= a.G; g += 4) {
-            const float v0 = pp[(size_t)g * gs], v1 = pp[(size_t)(g + 1) * gs], v2 = pp[(size_t)(g + 2) * gs],
-                        v3 = pp[(size_t)(g + 3) * gs];
-            acc = (((acc + v0) + v1) + v2) + v3;
+        if (a.fine) {
+            const float* pp = a.part + ((size_t)b * a.G * a.S * a.Lloc + l) * CPART + i;
+            for (int g = 0; g < a.G; ++g) {
+                const int np = min(a.npairs, (g + 1) * per) - g * per, nrun = (np + a.sub - 1) / a.sub;
+                const float* pg = pp + (size_t)g * a.S * gs;
+                float t = 0.f;
+                int s = 0;
+                for (; s + 4 <= nrun; s += 4) {
+                    const float v0 = pg[(size_t)s * gs], v1 = pg[(size_t)(s + 1) * gs], v2 = pg[(size_t)(s + 2) * gs],
+                                v3 = pg[(size_t)(s + 3) * gs];
+                    t = (((t + v0) + v1) + v2) + v3;
+                }
+                for (; s < nrun; ++s) t += pg[(size_t)s * gs];
+                acc += t;
+            }
+        } else {
+            const float* pp = a.part + ((size_t)b * a.G * a.Lloc + l) * CPART + i;
+            int g = 0;
+            for (; g + 4 <= a.G; g += 4) {
+                const float v0 = pp[(size_t)g * gs], v1 = pp[(size_t)(g + 1) * gs], v2 = pp[(size_t)(g + 2) * gs],
+                            v3 = pp[(size_t)(g + 3) * gs];
+                acc = (((acc + v0) + v1) + v2) + v3;
+            }
+            for (; g < a.G; ++g) acc += pp[(size_t)g * gs];
         }
-        for (; g < a.G; ++g) acc += pp[(size_t)g * gs];
         zs[i] = acc;
     }
     __syncthreads();

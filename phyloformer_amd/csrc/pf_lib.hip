@@ -237,6 +237,7 @@ struct pf_handle {
     float* pair_table = nullptr;  // [484][72] block-0 row-attention contributions per residue pair (k_embed)
     bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
     bool colstats_mfma = false;   // option "colstats_mfma": k_colstats2 (MFMA formulation) instead of k_colstats
+    int colstats_fine = -1;       // option "colstats_fine": k_colstats blocks per run (1) / per group (0) / by batch (-1)
     bool materialize_x0 = false;  // option "materialize_x0": k_embed writes x0 and block 0 reads it (round-1 path)
     bool main2 = false;           // option "main2": k_main2 (one wave per SIMD, two tiles, hand-placed hidden loop);
                                   // bit-identical to k_main but 4 % slower, so off by default
@@ -510,7 +511,9 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
     float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag, *spart, *outpart;
-    int G;
+    int G;             // pair groups of k_colstats
+    int sub, S, fine;  // runs of `sub` pairs, S per group; fine: one block per run instead of per group
+    int nparts() const { return fine ? G * S : G; }
 };
 constexpr int WS_BUFS = 10;
 
@@ -531,7 +534,24 @@ int colstats_groups(int /*B*/, int P, int Lloc) {
     return G;
 }
 
-size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
+// The whole plan: groups, the runs inside a group (shape only, like the groups: they fix the association of
+// the pair sums) and - the one batch-dependent choice, which does not change a bit of the result - whether a
+// block walks a group or a single run.  A lone alignment cannot fill the chip with groups (60 x 500: 128
+// blocks of 222 pairs = 0.165 ms per launch); by runs it can (1,184 blocks of <= 32 pairs).
+void colstats_plan(const pf_handle* h, int B, int P, int Lloc, Workspace* w) {
+    w->G = colstats_groups(B, P, Lloc);
+    const int per = (P + w->G - 1) / w->G;
+    // (measured at 60 x 500: folding every 32 pairs costs the batched walk 1 %, every 64 nothing; a lone
+    // alignment's launch takes 68 us either way, and k_colfin 18 / 11 us)
+    w->sub = per >= 128 ? 64 : per >= 64 ? 32 : 16;
+    w->S = (per + w->sub - 1) / w->sub;
+    // by groups once they fill the chip's 512 resident blocks (2 per CU), by runs below that
+    const long group_blocks = (long)B * ((Lloc + 31) / 32) * w->G;
+    const bool auto_fine = w->S > 1 && group_blocks < 512;
+    w->fine = h->colstats_mfma ? 0 : h->colstats_fine < 0 ? (int)auto_fine : (h->colstats_fine && w->S > 1);
+}
+
+size_t workspace_bytes(int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) {
     const size_t tok = (size_t)B * P * Lloc;
     size_t o = 0;
     off[0] = o; o = align_up(o + (tok + 32) * 64 * 4, 256);              // x (+ 32-token trash area)
@@ -539,7 +559,7 @@ size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
     off[2] = o; o = align_up(o + (tok + 32) * 4 * 4, 256);               // qcol (+ trash)
     off[3] = o; o = align_up(o + (size_t)B * P * SROW * 4, 256);         // srow
     off[4] = o; o = align_up(o + (size_t)B * P * MROW * 4, 256);         // mrow
-    off[5] = o; o = align_up(o + (size_t)B * G * Lloc * CPART * 4, 256); // part
+    off[5] = o; o = align_up(o + (size_t)B * nparts * Lloc * CPART * 4, 256); // part
     off[6] = o; o = align_up(o + (size_t)B * Lloc * 64 * 4, 256);        // ctx
     off[7] = o; o = align_up(o + (size_t)B * P * MFRAG_PER_PAIR * 16, 256); // mfrag
     const size_t ntiles = (size_t)(Lloc + 31) / 32;
@@ -550,8 +570,8 @@ size_t workspace_bytes(int B, int P, int Lloc, int G, size_t off[WS_BUFS]) {
 
 int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w, bool second = false) {
     size_t off[WS_BUFS];
-    w->G = colstats_groups(B, P, Lloc);
-    const size_t need = workspace_bytes(B, P, Lloc, w->G, off);
+    colstats_plan(h, B, P, Lloc, w);
+    const size_t need = workspace_bytes(B, P, Lloc, w->nparts(), off);
     char*& ws = second ? h->ws2 : h->ws;
     size_t& have = second ? h->ws2_bytes : h->ws_bytes;
     if (need > have) {
@@ -771,12 +791,13 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     {
         if (!h->colstats_mfma) {
             ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
-                           h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
+                           w.sub, w.S, w.fine, h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
             ProfScope ps(h, K_COLSTATS);
+            const unsigned nblk = (unsigned)(B * a.nchunks * w.nparts());
             if (k == 0 && x0_on_the_fly(h))
-                hipLaunchKernelGGL(k_colstats<true>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->cur, a);
+                hipLaunchKernelGGL(k_colstats<true>, dim3(nblk), dim3(256), 0, h->cur, a);
             else
-                hipLaunchKernelGGL(k_colstats<false>, dim3(B * a.nchunks * w.G), dim3(256), 0, h->cur, a);
+                hipLaunchKernelGGL(k_colstats<false>, dim3(nblk), dim3(256), 0, h->cur, a);
         } else {
             // experiment (tools/colstats_compare.py): both contractions on MFMA, 13 instead of 27.5 VALU
             // instructions per token, but no faster (0.96 vs 0.91 ms at batch 16, 0.145 vs 0.067 ms at batch 1)
@@ -799,9 +820,9 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         HIPCHK(h, hipGetLastError());
     }
     {
-        ColFinArgs a{w.part, w.ctx, d.col_wvT, d.col_bv, B, Lloc, w.G, (float)P};
+        ColFinArgs a{w.part, w.ctx, d.col_wvT, d.col_bv, B, Lloc, w.G, (float)P, P, w.sub, w.S, w.fine};
         ProfScope ps(h, K_COLFIN);
-        hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(256), 0, h->cur, a);
+        hipLaunchKernelGGL(k_colfin, dim3(B * Lloc), dim3(COLFIN_THREADS), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     if (h->debug_keep) {
@@ -1105,6 +1126,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "embed_mfma") h->embed_mfma = value != 0;
     else if (k == "colstats_mfma") h->colstats_mfma = value != 0;
+    else if (k == "colstats_fine") h->colstats_fine = value < 0 ? -1 : (value != 0);
     else if (k == "materialize_x0") h->materialize_x0 = value != 0;
     else if (k == "main2") h->main2 = value != 0;
     else if (k == "overlap") h->overlap = value != 0;
@@ -1299,8 +1321,8 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
         ShardRun r{};
         r.B = B; r.N = N; r.P = P; r.Lloc = hi - lo; r.L_total = L;
         size_t off[WS_BUFS];
-        r.w.G = colstats_groups(B, P, r.Lloc);
-        const size_t need = workspace_bytes(B, P, r.Lloc, r.w.G, off);
+        colstats_plan(h, B, P, r.Lloc, &r.w);
+        const size_t need = workspace_bytes(B, P, r.Lloc, r.w.nparts(), off);
         char* ws = nullptr; uint8_t* di = nullptr; float* dout = nullptr;
         hipError_t e1 = hipMalloc((void**)&ws, need), e2 = hipMalloc((void**)&di, (size_t)B * N * r.Lloc),
                    e3 = hipMalloc((void**)&dout, (size_t)B * P * sizeof(float));

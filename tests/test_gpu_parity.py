@@ -222,6 +222,24 @@ def test_batch_invariance_and_determinism(engines, golden):
     assert np.array_equal(e.forward(np.concatenate([g3, g3, g3]))[2], e.forward(g3)[0])
 
 
+def test_column_statistics_by_groups_or_by_runs_same_bits(weights, golden):
+    """k_colstats walks a pair group per block, or - when groups alone would leave the chip idle, e.g. a lone
+    alignment - one run of the group per block with k_colfin folding the runs (pf_lib.hip colstats_plan).
+    Both realise the same summation tree: identical bits, forced either way or chosen by batch size, also
+    where the last group is short and where a group is a single run."""
+    from phyloformer_amd.engine import Engine
+    g = golden("configs.npz")
+    cases = [g["c2_idx"], g["c3_idx"], simulate_batch(2, 23, 45, seed=5), simulate_batch(1, 5, 33, seed=6),
+             simulate_batch(1, 75, 40, seed=7)]
+    for idx in cases:
+        out = {}
+        for fine in (0, 1, -1):
+            with Engine(weights("pf"), 0) as e:
+                e.set_option("colstats_fine", fine)
+                out[fine] = e.forward(idx)
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[-1])
+
+
 def test_permutation_equivariance(engines):
     e = engines("pf")
     idx = simulate_batch(1, 9, 70, seed=21)[0]
