@@ -971,6 +971,14 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
     const int pr = blockIdx.x * 4 + sub;
     const bool ok = pr < a.npairs;
+    // the out_proj column of this thread first: its latency hides behind the partial sums (a lone
+    // alignment's forward is a chain of 26 such latencies)
+    float wo[4][16];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+        for (int d = 0; d < 16; ++d) wo[hh][d] = a.woT[(16 * hh + d) * 64 + c];
+    const float bvc = a.bv[c], biasc = a.bias[c], biascol = a.bias_col[c];
     if (ok) {
         // partial statistics are summed in index order: the association is a function of the shape only
         const float* sp = a.srow + (size_t)pr * a.nparts * SROW;
@@ -998,7 +1006,7 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
         const int hh = c >> 4;
         const float sk = s[68 + hh], sq = s[64 + hh];
         // (k / sum k)^T v, then q / mean(q): attention.py:183-192
-        ctx[sub][c] = (s[c] + a.bv[c] * sk) / sk * (a.L_total / sq);
+        ctx[sub][c] = (s[c] + bvc * sk) / sk * (a.L_total / sq);
     }
     __syncthreads();
     if (ok) {
@@ -1007,13 +1015,13 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
         for (int hh = 0; hh < 4; ++hh) {
             float acc = 0.f;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) acc = fmaf(a.woT[(16 * hh + d) * 64 + c], ctx[sub][16 * hh + d], acc);
+            for (int d = 0; d < 16; ++d) acc = fmaf(wo[hh][d], ctx[sub][16 * hh + d], acc);
             if (m) m[hh * 64 + c] = acc;
             mm[sub][hh][c] = acc;
         }
-        if (m) m[4 * 64 + c] = a.bias[c];
-        mm[sub][4][c] = a.bias[c];
-        mm[sub][5][c] = a.bias_col[c];
+        if (m) m[4 * 64 + c] = biasc;
+        mm[sub][4][c] = biasc;
+        mm[sub][5][c] = biascol;
     }
     __syncthreads();
     if (ok) {
@@ -1541,28 +1549,42 @@ struct ColFinArgs {
 constexpr int COLFIN_THREADS = 320;      // >= CPART: one value per thread
 __global__ void __launch_bounds__(COLFIN_THREADS) k_colfin(ColFinArgs a) {
     __shared__ float zs[CPART];
+    __shared__ float dp[4][64];
     const int site = blockIdx.x;  // b * Lloc + l
     const int b = site / a.Lloc, l = site - b * a.Lloc;
     const size_t gs = (size_t)a.Lloc * CPART;
     const int per = (a.npairs + a.G - 1) / a.G;
     const int i = threadIdx.x;
+    // the projection weights first (thread = output hd, a quarter of the 64 inputs): their latency hides
+    // behind the partial sums
+    const int hd = i & 63, quarter = (i >> 6) & 3;
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = a.wvT[(16 * quarter + k) * 64 + hd];
     if (i < CPART) {
-        // partials are summed in group order (fixed association); four loads in flight per thread
+        // partials are summed in run, then group order (fixed association); up to eight loads in flight
         float acc = 0.f;
         if (a.fine) {
             const float* pp = a.part + ((size_t)b * a.G * a.S * a.Lloc + l) * CPART + i;
-            for (int g = 0; g < a.G; ++g) {
-                const int np = min(a.npairs, (g + 1) * per) - g * per, nrun = (np + a.sub - 1) / a.sub;
-                const float* pg = pp + (size_t)g * a.S * gs;
-                float t = 0.f;
-                int s = 0;
-                for (; s + 4 <= nrun; s += 4) {
-                    const float v0 = pg[(size_t)s * gs], v1 = pg[(size_t)(s + 1) * gs], v2 = pg[(size_t)(s + 2) * gs],
-                                v3 = pg[(size_t)(s + 3) * gs];
-                    t = (((t + v0) + v1) + v2) + v3;
+            for (int g = 0; g < a.G; g += 2) {
+                const bool two = g + 1 < a.G;
+                const int n0 = (min(a.npairs, (g + 1) * per) - g * per + a.sub - 1) / a.sub;
+                const int n1 = two ? (min(a.npairs, (g + 2) * per) - (g + 1) * per + a.sub - 1) / a.sub : 0;
+                const float* p0 = pp + (size_t)g * a.S * gs;
+                const float* p1 = p0 + (size_t)a.S * gs;
+                float t0 = 0.f, t1 = 0.f;
+                for (int s = 0; s < max(n0, n1); s += 4) {
+                    float v[4], u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {      // (uniform conditions; x + 0 leaves every bit of x)
+                        v[q] = s + q < n0 ? p0[(size_t)(s + q) * gs] : 0.f;
+                        u[q] = s + q < n1 ? p1[(size_t)(s + q) * gs] : 0.f;
+                    }
+                    t0 = (((t0 + v[0]) + v[1]) + v[2]) + v[3];
+                    t1 = (((t1 + u[0]) + u[1]) + u[2]) + u[3];
                 }
-                for (; s < nrun; ++s) t += pg[(size_t)s * gs];
-                acc += t;
+                acc += t0;
+                if (two) acc += t1;
             }
         } else {
             const float* pp = a.part + ((size_t)b * a.G * a.Lloc + l) * CPART + i;
@@ -1577,11 +1599,17 @@ __global__ void __launch_bounds__(COLFIN_THREADS) k_colfin(ColFinArgs a) {
         zs[i] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int hd = threadIdx.x, hh = hd >> 4;
+    if (i < 256) {
+        const float* z = zs + (hd >> 4) * 64 + 16 * quarter;
         float acc = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) acc = fmaf(a.wvT[c * 64 + hd], zs[hh * 64 + c], acc);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(w[k], z[k], acc);
+        dp[quarter][hd] = acc;
+    }
+    __syncthreads();
+    if (i < 64) {
+        const int hh = hd >> 4;
+        const float acc = ((dp[0][hd] + dp[1][hd]) + dp[2][hd]) + dp[3][hd];
         const float sq = zs[256 + hh], sk = zs[260 + hh];
         a.ctx[(size_t)site * 64 + hd] = (acc + a.bv[hd] * sk) / sk * (a.P / sq);
     }
