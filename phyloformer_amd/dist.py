@@ -89,6 +89,17 @@ def init_engine_comm(engine, group=None) -> Tuple[int, int]:
     if world == 1:
         engine.comm_init(None, 0, 1)
         return 0, 1
+    if group is not None and hasattr(engine, "comm_info"):
+        # ncclCommInitRank blocks until every rank has entered it: make sure beforehand that every rank can
+        # load a usable librccl, so that a rank that cannot is reported by all instead of hanging the others
+        try:
+            engine.comm_info()
+            mine = ""
+        except Exception as exc:  # noqa: BLE001 - reported to every rank below
+            mine = f"rank {rank}: {type(exc).__name__}: {exc}"
+        bad = [m for m in group.allgather(mine) if m]
+        if bad:
+            raise RuntimeError("RCCL cannot be loaded on every rank (" + "; ".join(bad) + ")")
     uid, why = None, ""
     if rank == 0:
         try:

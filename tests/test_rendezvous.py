@@ -13,8 +13,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _FakeEngine:
     """What dist.init_engine_comm needs from an Engine."""
 
-    def __init__(self, rank, fail_uid=False):
-        self.rank_, self.fail_uid, self.inited = rank, fail_uid, None
+    def __init__(self, rank, fail_uid=False, no_rccl=False):
+        self.rank_, self.fail_uid, self.no_rccl, self.inited = rank, fail_uid, no_rccl, None
+
+    def comm_info(self):
+        if self.no_rccl:
+            raise RuntimeError("librccl.so.1 is bound to another HIP runtime")
+        return {"library": "/opt/rocm/lib/librccl.so.1", "version": 22707}
 
     def unique_id(self):
         if self.fail_uid:
@@ -35,7 +40,8 @@ def _worker(rank, world, key, tmp, fail_uid, q):
             ranks = g.allgather(rank)
             mx, mn = g.allreduce_max(float(rank) + 0.5), g.allreduce_min(float(rank) + 0.5)
             g.barrier()
-            eng = _FakeEngine(rank, fail_uid=fail_uid)
+            # fail_uid = "probe": the LAST rank cannot load librccl - found out before anyone blocks in comm_init
+            eng = _FakeEngine(rank, fail_uid=fail_uid is True, no_rccl=fail_uid == "probe" and rank == world - 1)
             try:
                 pfdist.init_engine_comm(eng, g)
                 comm = ("ok", eng.inited)
@@ -47,7 +53,7 @@ def _worker(rank, world, key, tmp, fail_uid, q):
         q.put((rank, "EXC", repr(exc)))
 
 
-@pytest.mark.parametrize("world,fail_uid", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,fail_uid", [(2, False), (3, False), (2, True), (3, "probe")])
 def test_tcp_group_collectives_and_comm_bootstrap(world, fail_uid, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -66,7 +72,7 @@ def test_tcp_group_collectives_and_comm_bootstrap(world, fail_uid, tmp_path):
         if fail_uid:
             # rank 0 broadcast the sentinel instead of leaving its peers in a broadcast that never comes:
             # every rank raises the same error and they all agree
-            assert comm[0] == "error" and "unique id" in comm[1]
+            assert comm[0] == "error" and ("unique id" in comm[1] if fail_uid is True else f"rank {world - 1}" in comm[1])
             assert flags == ["error"] * world
         else:
             uid, r, w = comm[1]
