@@ -21,9 +21,9 @@
 //                p = 2^(s - m) online, P split hi/lo in registers -> B operand of O^T += V^T P^T.
 //   k_mha_out    out_proj on 32-token tiles, fp32 result.
 //
-// MFMA shape: v_mfma_f32_32x32x16_bf16 everywhere.  D = 16 fills K of the QK^T product exactly; for
-// PV only 16 of the 32 M rows (the head's channels) are useful — the kernel is bound by exp2/VALU
-// (16 scores per lane per tile), not by MFMA, so the half-empty tile costs nothing measurable.
+// MFMA shapes: v_mfma_f32_32x32x16_bf16 for the projections and QK^T (D = 16 fills its K exactly);
+// v_mfma_f32_16x16x32_bf16 for PV (M = the head's 16 channels, K = the 32 keys of a tile, two N = 16 query
+// halves): the P fragments reach its B layout with one v_permlane16_swap per register pair.
 #pragma once
 
 namespace pfk {
@@ -191,13 +191,40 @@ __global__ void __launch_bounds__(256) k_mha_qkv(MhaArgs a) {
                 for (int i = 0; i < 8; ++i) v[i] = acc[8 * s2 + i];
                 bf16x8 fh, fl;
                 split8(v, fh, fl);
-                const size_t o = ((((size_t)row * MHA_H + hd) * a.ntiles + kt) * 16 + d) * 4 + s2 * 2 + h;
+                // A operand of v_mfma_f32_16x16x32_bf16: lane 16 g + d holds 8 keys of channel d; key group
+                // g = 2 h + s2 is the set kmap(8 s2 .. 8 s2 + 7, h) - the order the P fragments of k_mha_attn
+                // arrive in after their permlane16 swap
+                const size_t o = (((size_t)row * MHA_H + hd) * a.ntiles + kt) * 64 + 16 * (2 * h + s2) + d;
                 a.vp[o] = fh;
                 a.vp[plane_v + o] = fl;
             }
         }
     }
 }
+
+// x <-> y exchange of 16-lane rows: x.row1 <-> y.row0, x.row3 <-> y.row2 (tools/mfma16_test.hip).  With x, y
+// the lane's values for two key groups, x' then holds queries 0-15 in every row and y' queries 16-31.
+__device__ __forceinline__ void swap_rows16(unsigned& x, unsigned& y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0]; y = r[1];
+}
+__device__ __forceinline__ void swap_rows16(float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
+    swap_rows16(a, b);
+    x = __builtin_bit_cast(float, a); y = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ void swap_rows16(bf16x8& x, bf16x8& y) {
+    u32x4 a = __builtin_bit_cast(u32x4, x), b = __builtin_bit_cast(u32x4, y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned u = a[i], v = b[i];
+        swap_rows16(u, v);
+        a[i] = u; b[i] = v;
+    }
+    x = __builtin_bit_cast(bf16x8, a); y = __builtin_bit_cast(bf16x8, b);
+}
+#define PF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+constexpr float MHA_DEFER = 6.f;   // the running maximum is raised only when a tile exceeds it by 2^6
 
 __global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
     // per key tile: K hi / mid / lo, V hi / lo: 64 fragments of 16 B each
@@ -229,10 +256,9 @@ __global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
     fetch(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x16 o;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o[j] = 0.f;
-    float m_run = -INFINITY, lsum = 0.f;
+    // O^T for queries 0-15 / 16-31 of the tile: lane 16 g + n holds channels 4 g .. 4 g + 3 of query n
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    float m_ref = -INFINITY, lsum = 0.f;
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         if (st + 1 < nst) fetch(st + 1, buf ^ 1);
@@ -240,54 +266,79 @@ __global__ void __launch_bounds__(256) k_mha_attn(MhaArgs a) {
         for (int k = 0; k < ktn; ++k) {
             const bf16x8 kh = stage[buf][k][0][2 * t + h], km = stage[buf][k][1][2 * t + h],
                          kl = stage[buf][k][2][2 * t + h];
+            // s[j] = S[key kmap(j,h)][query t], log2 units.  The six passes of mfma6 written out with the
+            // accumulator in VGPRs: hipcc would park it in AGPRs and pay a v_accvgpr_read per score (16 of the
+            // ~140 instructions of a tile).  The trailing s_nop is the 8-pass XDL-write -> VALU-read distance
+            // (11 wait states), which hipcc cannot see inside an asm statement.
             f32x16 s;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s[j] = 0.f;
-            mfma6(s, kh, km, kl, qh, qm, ql);               // s[j] = S[key kmap(j,h)][query t], log2 units
+            asm volatile(
+                "v_mfma_f32_32x32x16_bf16 %0, %2, %5, 0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %1, %6, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0\n\t"
+                "s_nop 10"
+                : "=&v"(s) : "v"(kh), "v"(km), "v"(kl), "v"(qh), "v"(qm), "v"(ql));
             const int key0 = (st * MHA_KB + k) * 32;
             if (key0 + 32 > a.C) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if (key0 + kmap(j, h) >= a.C) s[j] = -INFINITY;
             }
-            float mx = s[0];
+            float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);      // (v_max3_f32)
 #pragma unroll
-            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, s[j]);
+            for (int j = 3; j < 15; j += 2) mx = fmaxf(fmaxf(mx, s[j]), s[j + 1]);
+            mx = fmaxf(mx, s[15]);
             mx = fmaxf(mx, pair_other(mx, h));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            float p[16], ps = 0.f;
+            // Deferred rescaling: the reference maximum moves only when some query of the tile beats it by
+            // 2^MHA_DEFER (always on the first tile); p <= 2^MHA_DEFER otherwise, which fp32 / the split carry
+            // exactly as well.  Wave-uniform branch; lanes that did not trip it rescale by alpha <= 1 too.
+            if (__builtin_amdgcn_ballot_w64(mx > m_ref + MHA_DEFER) != 0) {
+                const float m_new = fmaxf(m_ref, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+                m_ref = m_new;
+                lsum *= alpha;
+                float a0 = alpha, a1 = alpha;               // alpha of query n / 16 + n for every row of lanes
+                swap_rows16(a0, a1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                p[j] = __builtin_amdgcn_exp2f(s[j] - m_new);
-                ps += p[j];
+                for (int i = 0; i < 4; ++i) { o0[i] *= a0; o1[i] *= a1; }
             }
-            lsum = fmaf(lsum, alpha, ps);
+            float p[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= alpha;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 ph, pl;
-                split8(&p[8 * s2], ph, pl);
-                const int vi = (t & 15) * 4 + s2 * 2 + h;
-                const bf16x8 vh = stage[buf][k][3][vi], vl = stage[buf][k][4][vi];
-                mfma3(o, vh, vl, ph, pl);                  // o[j<8] = O^T[d = kmap(j,h)][query t]
-            }
+            for (int j = 0; j < 16; ++j) p[j] = __builtin_amdgcn_exp2f(s[j] - m_ref);
+            lsum += (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) +
+                    (((p[8] + p[9]) + (p[10] + p[11])) + ((p[12] + p[13]) + (p[14] + p[15])));
+            bf16x8 ph0, pl0, ph1, pl1;
+            split8(&p[0], ph0, pl0);                        // keys kmap(0..7, h)
+            split8(&p[8], ph1, pl1);                        // keys kmap(8..15, h)
+            swap_rows16(ph0, ph1);                          // -> B operands: queries 0-15 | 16-31, key group per row
+            swap_rows16(pl0, pl1);
+            const bf16x8 vh = stage[buf][k][3][lane], vl = stage[buf][k][4][lane];
+            // O^T += V^T P^T, small terms first, the two query halves alternating; accumulators in VGPRs (their
+            // next VALU reader - a rescale or the epilogue - is more than the 7 wait states of a 4-pass MFMA away)
+            asm volatile(
+                "s_nop 1\n\t"                               // (the P fragments were just written by v_permlane16_swap)
+                "v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\t"
+                "v_mfma_f32_16x16x32_bf16 %1, %3, %6, %1\n\t"
+                "v_mfma_f32_16x16x32_bf16 %0, %2, %5, %0\n\t"
+                "v_mfma_f32_16x16x32_bf16 %1, %2, %7, %1\n\t"
+                "v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\t"
+                "v_mfma_f32_16x16x32_bf16 %1, %2, %6, %1"
+                : "+v"(o0), "+v"(o1) : "v"(vh), "v"(vl), "v"(ph0), "v"(pl0), "v"(ph1), "v"(pl1));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     const float l = lsum + pair_other(lsum, h);
-    const float inv = 1.f / l;
-    const int c = (qb * 4 + w) * 32 + t;
-    if (qb * 4 + w < a.ntiles && c < a.C) {
-        float* dst = a.att + ((size_t)row * a.C + c) * 64 + hd * 16 + 4 * h;
-        f32x4 v0, v1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i] = o[i] * inv; v1[i] = o[4 + i] * inv; }
-        *reinterpret_cast<f32x4*>(dst) = v0;
-        *reinterpret_cast<f32x4*>(dst + 8) = v1;
+    float i0 = 1.f / l, i1 = i0;
+    swap_rows16(i0, i1);
+    const int n = lane & 15, g = lane >> 4;
+    const int c0 = (qb * 4 + w) * 32 + n;
+    if (qb * 4 + w < a.ntiles) {
+        float* dst = a.att + ((size_t)row * a.C + c0) * 64 + hd * 16 + 4 * g;
+        if (c0 < a.C) *reinterpret_cast<f32x4*>(dst) = o0 * i0;
+        if (c0 + 16 < a.C) *reinterpret_cast<f32x4*>(dst + 16 * 64) = o1 * i1;
     }
 }
 
