@@ -911,26 +911,48 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
         const uint8_t* rj = a.idx + ((size_t)b * a.N + a.pair_j[p]) * a.Lloc;
         const size_t row0 = (size_t)task * a.Lloc;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acce = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int l0 = 0; l0 < a.Lloc; l0 += 4) {
-            const int l = l0 + sg;
-            const bool valid = l < a.Lloc;
-            const int lc = valid ? l : a.Lloc - 1;
-            const int ra = ri[lc], rb = rj[lc];
-            const float* tr = tab + (ra * 22 + rb) * PAIRTAB_W;
-            const f32x4 s = *reinterpret_cast<const f32x4*>(tr + 4 * cl);
-            const f32x4 e = *reinterpret_cast<const f32x4*>(tr + 64 + 4 * (cl & 1));   // even lanes q', odd k'
-            if (valid) {
-                acc += s;
-                acce += e;
-                const size_t tok = row0 + l;
-                if (a.x) {       // wave-uniform: only the round-1 path / the debug tap materialise x0
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(emb + ra * 64 + 4 * cl);
-                    const f32x4 xb = *reinterpret_cast<const f32x4*>(emb + rb * 64 + 4 * cl);
-                    *reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * cl) = xa + xb;
+        // Residues: the wave fetches 64 consecutive sites of both sequences with one byte pair per lane, one
+        // block ahead, and an iteration takes its residues from a lane of that register (ds_bpermute) - a
+        // dependent byte load per iteration (global -> LDS address -> table row) made the walk latency-bound
+        // at ~480 cycles per four sites.  Same sites per lane in the same order: same sums.
+        // (what travels is the row number of the residue pair in the table: one multiply-add per site instead
+        // of one per lane and iteration)
+        auto fetch = [&](int blk) {
+            const int l = min(blk * 64 + lane, a.Lloc - 1);
+            return (int)ri[l] * 22 + (int)rj[l];
+        };
+        const int nblk = (a.Lloc + 63) >> 6;
+        int cur = fetch(0);
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int nxt = fetch(min(blk + 1, nblk - 1));
+            const int lbase = blk * 64;
+            const int nit = min(16, (a.Lloc - lbase + 3) >> 2);
+            auto site = [&](int it, bool valid) {
+                const int l = lbase + 4 * it + sg;
+                const int rr = __shfl(cur, 4 * it + sg);
+                const float* tr = tab + rr * PAIRTAB_W;
+                const f32x4 s = *reinterpret_cast<const f32x4*>(tr + 4 * cl);
+                const f32x4 e = *reinterpret_cast<const f32x4*>(tr + 64 + 4 * (cl & 1));   // even lanes q', odd k'
+                if (valid) {
+                    acc += s;
+                    acce += e;
+                    const size_t tok = row0 + l;
+                    if (a.x) {       // wave-uniform: only the round-1 path / the debug tap materialise x0
+                        const int ra = rr / 22, rb = rr - 22 * ra;
+                        const f32x4 xa = *reinterpret_cast<const f32x4*>(emb + ra * 64 + 4 * cl);
+                        const f32x4 xb = *reinterpret_cast<const f32x4*>(emb + rb * 64 + 4 * cl);
+                        *reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * cl) = xa + xb;
+                    }
+                    if (cl == 0) *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = e;
                 }
-                if (cl == 0) *reinterpret_cast<f32x4*>(a.qrow + tok * 4) = e;
+            };
+            if (lbase + 64 <= a.Lloc) {             // a full block: no per-lane validity
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) site(it, true);
+            } else {
+                for (int it = 0; it < nit; ++it) site(it, lbase + 4 * it + sg < a.Lloc);   // (a lane past the end reads the clamped last site, unused)
             }
+            cur = nxt;
         }
         // sum the four site sub-groups (lanes 16 and 32 apart)
 #pragma unroll
