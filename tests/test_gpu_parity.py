@@ -129,6 +129,24 @@ def test_oracle_parity_small_shapes(engines, weights):
         assert err <= _bound(scale), (n, l)
 
 
+def test_oracle_parity_shapes_around_the_kernels_block_sizes(engines, weights):
+    """Site counts around the 32-site tile, the 64-site residue block of k_embed and the 16 / 32 / 64-pair
+    runs of k_colstats (one group, several groups, a short last group), batched and alone - the lone
+    alignment takes the run-sized column-statistics blocks, the batch the group-sized ones."""
+    e = engines("pf")
+    w = weights("pf").tensors
+    cases = [(9, 63, 1, 11), (9, 64, 2, 12), (9, 65, 1, 13), (6, 127, 3, 14), (6, 129, 1, 15), (17, 40, 1, 16),
+             (17, 40, 4, 17), (24, 33, 1, 18), (33, 12, 1, 19), (40, 70, 1, 20)]
+    for (n, l, b, seed) in cases:
+        idx = simulate_batch(b, n, l, seed=seed, gaps=(seed % 3 == 0))
+        got = e.forward(idx)
+        want = O.forward_batch(w, idx)
+        err, scale = _record(f"oracle {n}x{l} batch {b} pf", got, want)
+        assert err <= _bound(scale), (n, l, b)
+        if b > 1:       # and the same bits one by one
+            assert np.array_equal(np.stack([e.forward(x) for x in idx]), got)
+
+
 def test_reference_goldens_all_checkpoints(engines, golden, repo):
     """The 20 test MSAs x 5 checkpoints against the reference's own outputs."""
     g = golden("e2e_testdata.npz")
