@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event bracketing of kernels")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="run every pass with the batch on one stream (engine options two_streams / overlap = 0): "
+                         "launches are serial, so a rocprofv3 --stats summary of this command agrees with roofline.avg_launch_ms")
     ap.add_argument("--force-dist", action="store_true",
                     help="test aid: run the N>1 code path (rendezvous, RCCL communicator, 7 all-reduces "
                          "per step) even with one rank")
@@ -223,19 +226,33 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         dt = time.perf_counter() - t0
         return group.allreduce_max(dt) if group is not None else dt
 
+    def streams(two):
+        # the default schedule runs a batch as two half-batches on two streams (single GPU: each half fills the
+        # other's kernel tails; site-sharded: a half's all-reduce runs under the other half's kernels)
+        eng.set_option("two_streams", 1 if two else 0)
+        eng.set_option("overlap", 1 if two else 0)
+
+    streams(not args.one_stream)
     for _ in range(args.warmup):
         step()
-    if not args.no_profile:
-        eng.set_option("profile", 2)   # HIP events around every k_main launch only (see header)
-        eng.profile_reset()
     sampler = PowerSampler() if (rank == 0 and not args.no_power) else None
     if sampler:
         sampler.__enter__()
     dt = timed(step, args.steps)
-    prof = {}
+    # The roofline of the dominant kernel is taken in a second timed region of the same length with the batch
+    # on ONE stream: there a k_main launch has the chip to itself and covers the whole batch, so its HIP-event
+    # duration is the kernel's own.  (In the two-stream schedule a half-batch launch shares the CUs with the
+    # other half's column statistics and its bracket measures that mix.)
+    prof, dt_one = {}, None
     if not args.no_profile:
+        streams(False)
+        step()
+        eng.set_option("profile", 2)   # HIP events around every k_main launch only (see header)
+        eng.profile_reset()
+        dt_one = timed(step, args.steps)
         prof["main"] = eng.profile_get("main")
         eng.set_option("profile", 0)
+        streams(not args.one_stream)
     result = np.empty((B, P), np.float32)
     eng.d2h(result, d_out)
     assert np.isfinite(result).all() and (result > 0).all()
@@ -264,6 +281,9 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
                     "traffic_source": f"{PMC_FILE}: separate rocprofv3 --pmc passes of this build (tools/pmc.sh), "
                                       "scaled by tokens; not measured by this run",
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_main,
+                    "schedule": "second timed region of the same steps with the batch on one stream (a launch covers "
+                                "the whole batch and has the chip to itself); `value` is the default two-stream schedule"
+                                if not args.one_stream else "one stream (--one-stream)",
                     "note": "algorithmic flops (1 pass); the split-bf16 scheme issues 3 MFMA passes, "
                             "so frac tops out at 1/3"}
         line = {
@@ -276,6 +296,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
                        "global_batch": B if args.shard == "sites" else B * world,
                        "n_seqs": N, "n_sites": L, "parallelism": f"{args.shard}-sharded x{world}",
                        "device": info["name"].strip()},
+            "value_one_stream": round(total_alignments / dt_one, 3) if dt_one else None,
             "value_host_buffers": round(total_alignments / dt_host, 3),
             "value_host_buffers_note": "same steps through pf_forward[_sharded] with host buffers: H2D of the "
                                        "indices + D2H of the distances + one synchronisation per call "

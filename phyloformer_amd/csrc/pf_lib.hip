@@ -263,6 +263,9 @@ struct pf_handle {
     int rank = 0, world = 1;
     bool sharded_call = false;   // set by pf_forward_sharded* for the duration of the call
     bool reducing = false;       // this forward issues collectives (persistent kernels leave reserve_cus CUs free)
+    bool two_streams = true;     // option "two_streams": forwards of >= 2 alignments run as two free-running half-batches
+                                 // on two streams, each filling the other's kernel tails and small kernels (+2.5 %
+                                 // at 60 x 500 batch 16, +4.7 % at 60 x 2000 batch 4; same bits: tools/two_streams_compare.py)
     // profiling
     std::vector<ProfSlot> pending;
     std::vector<hipEvent_t> free_events;
@@ -851,7 +854,11 @@ bool reduces_now(const pf_handle* h) { return h->sharded_call && (h->world > 1 |
 
 // How a chunk of B alignments is cut for the overlapped schedule: two halves when collectives run.  Every
 // rank must cut identically (one all-reduce sequence per half), so this depends on B and the options only.
-int halves_of(const pf_handle* h, int B) { return (reduces_now(h) && h->overlap && B >= 2) ? 2 : 1; }
+int halves_of(const pf_handle* h, int B) {
+    if (B < 2) return 1;
+    if (reduces_now(h)) return h->overlap ? 2 : 1;
+    return (h->two_streams && !h->debug_keep) ? 2 : 1;   // (debug taps are kept per name: one half only)
+}
 
 int ensure_second_stream(pf_handle* h) {
     if (h->stream2) return PF_OK;
@@ -866,6 +873,8 @@ int ensure_second_stream(pf_handle* h) {
 // half (RCCL kernels on a few CUs; the persistent compute kernels leave `reserve_cus` free) runs beside the
 // column statistics / FFN of the other.  Each half is an independent forward, so the results are those of
 // the serial schedule bit for bit; the collectives double in number (2 x (n_blocks + 1)) and halve in size.
+// Single-GPU forwards are cut the same way (option "two_streams"): the halves run free, and whichever is in a
+// kernel tail, a small kernel or a launch gap leaves its CUs to the other.
 int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, int L_total, float* d_out) {
     const int P = N * (N - 1) / 2;
     const bool reduces = reduces_now(h);
@@ -1130,6 +1139,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "materialize_x0") h->materialize_x0 = value != 0;
     else if (k == "main2") h->main2 = value != 0;
     else if (k == "overlap") h->overlap = value != 0;
+    else if (k == "two_streams") h->two_streams = value != 0;
     else if (k == "reserve_cus") h->reserve_cus = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128));
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;

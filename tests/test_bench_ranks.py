@@ -99,17 +99,22 @@ def test_bench_rank_logic_world2(fail_comm_on, tmp_path):
         # sites 0..22 on rank 0, 23..44 on rank 1 (ceil split), global batch = batch x world
         for rank, (lo, hi) in enumerate([(0, 23), (23, 45)]):
             steps = [e for e in res[rank][0] if e[0] == "sharded"]
-            assert len(steps) == 4 and all(e == ("sharded", 4, 6, lo, hi, 45) for e in steps)
+            # warm-up + 3 timed steps on two streams, then 1 + 3 with the batch on one stream (roofline region)
+            assert len(steps) == 8 and all(e == ("sharded", 4, 6, lo, hi, 45) for e in steps)
+            opts = [e[1:] for e in res[rank][0] if e[0] == "opt" and e[1] in ("two_streams", "overlap")]
+            assert opts == [("two_streams", 1), ("overlap", 1), ("two_streams", 0), ("overlap", 0),
+                            ("two_streams", 1), ("overlap", 1)]
             assert ("h2d", (4, 6, hi - lo)) in res[rank][0]
         assert line["config"]["parallelism"] == "sites-sharded x2" and line["config"]["global_batch"] == 4
         assert line["config"]["rccl"]["library"].endswith("librccl.so.1")
-        assert line["roofline"]["launches"] == 6 * 4 and line["roofline"]["traffic_source"].startswith("profiles/")
+        assert line["roofline"]["launches"] == 6 * 8 and line["roofline"]["traffic_source"].startswith("profiles/")
+        assert line["value_one_stream"] > 0 and "one stream" in line["roofline"]["schedule"]
     else:
         # rank 1's communicator failed: BOTH ranks destroy theirs and shard whole alignments instead
         for rank in (0, 1):
             log = res[rank][0]
             assert ("comm_destroy",) in log
             assert not [e for e in log if e[0] == "sharded"]
-            assert len([e for e in log if e == ("plain", 2, 6, 45)]) == 4
+            assert len([e for e in log if e == ("plain", 2, 6, 45)]) == 8
         assert line["config"]["parallelism"] == "alignments-sharded x2" and line["config"]["global_batch"] == 4
         assert "RCCL init failed" in line["config"]["note"]
