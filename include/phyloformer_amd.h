@@ -106,7 +106,8 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "main2"      int   1 = k_main2 (one wave per SIMD, two tiles in flight, hand-placed hidden loop) instead of
  *                      the two-waves-per-SIMD k_main; same results bit for bit, measured 4 % slower (default 0)
  *   "two_streams" int  0 = a batch runs on one stream; default 1: forwards of >= 2 alignments run as two
- *                      independent half-batches on two streams (same results bit for bit, a few % faster)
+ *                      independent half-batches on two streams (same results bit for bit, a few % faster);
+ *                      environment PF_TWO_STREAMS=0/1 sets the initial value (A/B runs of whole programs)
  *   "overlap"    int   0 = site-sharded forwards issue one collective per block for the whole batch instead of
  *                      two half-batches on two streams
  *   "reserve_cus" int  CUs the persistent kernels leave to the RCCL kernels while collectives run (default 8)

@@ -118,6 +118,11 @@ def main(argv=None):
     if args.batch != 1:
         from phyloformer_amd.engine import Engine
         engines += [Engine(model.weights, device=args.device) for _ in range(max(1, args.gpu_streams) - 1)]
+    if len(engines) > 1:
+        # several engines already keep several streams busy; each splitting its batches over two more only adds
+        # contention (tools/cli_bench.py, same box: 505 against 498 alignments/s)
+        for e in engines:
+            e.set_option("two_streams", 0)
     runner = scheduler.DirectoryRunner(engines, out_dir, trees=args.trees, batch=args.batch,
                                        io_threads=args.io_threads, native_io=not args.python_io,
                                        progress=bar.update if bar is not None else None)

@@ -1057,6 +1057,7 @@ static int open_device(int device, pf_handle** out) {
                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device < 0 || device >= ndev) return fail(nullptr, PF_EINVAL, "device %d out of range (have %d)", device, ndev);
     pf_handle* h = new pf_handle();
+    if (const char* e = getenv("PF_TWO_STREAMS")) h->two_streams = atoi(e) != 0;   // A/B runs of whole programs
     h->device = device;
     int rc = PF_OK;
     do {
