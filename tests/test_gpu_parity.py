@@ -258,6 +258,31 @@ def test_column_statistics_by_groups_or_by_runs_same_bits(weights, golden):
         assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[-1])
 
 
+def test_two_stream_schedule_same_bits(weights, golden):
+    """A batch of >= 2 alignments runs as two half-batches on two streams by default (option two_streams);
+    the halves are independent forwards, so the distances are those of the one-stream schedule bit for bit -
+    for even and odd batches, and with back-to-back asynchronous forwards sharing the two workspaces."""
+    from phyloformer_amd.engine import Engine
+    g = golden("configs.npz")
+    for idx in (g["c2_idx"], np.concatenate([g["c2_idx"], g["c2_idx"][:2]]), simulate_batch(2, 31, 90, seed=9)):
+        out = {}
+        for ts in (0, 1):
+            with Engine(weights("pf"), 0) as e:
+                e.set_option("two_streams", ts)
+                out[ts] = e.forward(idx)
+                if ts:
+                    B, n, l = idx.shape
+                    P = n * (n - 1) // 2
+                    d_idx, d_out = e.malloc(idx.nbytes), e.malloc(B * P * 4)
+                    e.h2d(d_idx, np.ascontiguousarray(idx))
+                    for _ in range(3):
+                        e.forward_device(d_idx, B, n, l, d_out)
+                    again = np.empty((B, P), np.float32)
+                    e.d2h(again, d_out)
+                    assert np.array_equal(again, out[1])
+        assert np.array_equal(out[0], out[1])
+
+
 def test_permutation_equivariance(engines):
     e = engines("pf")
     idx = simulate_batch(1, 9, 70, seed=21)[0]
