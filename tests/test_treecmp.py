@@ -82,13 +82,13 @@ def test_nj_matches_fastme_nj_goldens(repo, golden):
         assert treecmp.branch_score(ref, clamped) <= neg + 1e-7, stem
 
 
-def _tree_check(repo, golden, to_tree):
-    gold = golden("e2e_testdata.npz")
+def _tree_check(repo, golden, to_tree, source="e2e_testdata.npz", key="pf/{}"):
+    gold = golden(source)
     rows = []
     for name in sorted(os.listdir(os.path.join(repo, "data/testdata/msas"))):
         stem = name[:-3]
         _idx, ids = fasta.load_alignment(os.path.join(repo, "data/testdata/msas", name))
-        dm = vec_to_matrix(gold[f"pf/{stem}"], len(ids)).astype(np.float64)
+        dm = vec_to_matrix(gold[key.format(stem)], len(ids)).astype(np.float64)
         true = treecmp.parse_newick(open(os.path.join(repo, "data/testdata/trees", stem + ".nwk")).read())
         est = treecmp.parse_newick(to_tree(dm, ids))
         rows.append(treecmp.robinson_foulds(true, est) + (treecmp.branch_score(true, est),))
@@ -118,3 +118,38 @@ def test_end_to_end_tree_check_with_fastme(repo, golden, tmp_path):
         return (tmp_path / "t.nwk").read_text()
     rf, nrf, kf = _tree_check(repo, golden, fastme)
     assert rf == pytest.approx(11.2) and nrf == pytest.approx(0.1837, abs=5e-4) and kf == pytest.approx(0.3935, abs=5e-4)
+
+
+def _fastme_tree(tmp_path, dm, ids):
+    import subprocess
+    from phyloformer_amd.hostio import format_phylip
+    n = len(ids)
+    (tmp_path / "m.phy").write_bytes(format_phylip(dm[np.triu_indices(n, 1)], ids))
+    subprocess.run([FASTME, "-i", str(tmp_path / "m.phy"), "-o", str(tmp_path / "t.nwk"), "--nni", "--spr"],
+                   check=True, capture_output=True)
+    return (tmp_path / "t.nwk").read_text()
+
+
+def test_gpu_distances_give_the_reference_distances_trees(repo, golden, tmp_path):
+    """tests/golden/gpu_distances_r02.npz = what `infer_alns.py models/pf.ckpt data/testdata/msas` wrote on an
+    MI355X (round 2, as printed in the .phy files).  They differ from the reference's distances by at most
+    1.2e-5, and the trees built from them are the trees built from the reference's: same neighbour-joining
+    topology and the same summary against the true trees - with the build's NJ here, and with the README's
+    FastME pipeline where the reference checkout (its binary) is present."""
+    gpu, ref = golden("gpu_distances_r02.npz"), golden("e2e_testdata.npz")
+    for name in sorted(os.listdir(os.path.join(repo, "data/testdata/msas"))):
+        stem = name[:-3]
+        _idx, ids = fasta.load_alignment(os.path.join(repo, "data/testdata/msas", name))
+        assert np.abs(gpu[stem] - ref[f"pf/{stem}"]).max() <= 2e-5
+        a = treecmp.parse_newick(neighbor_joining(vec_to_matrix(gpu[stem], len(ids)).astype(np.float64), ids))
+        b = treecmp.parse_newick(neighbor_joining(vec_to_matrix(ref[f"pf/{stem}"], len(ids)).astype(np.float64), ids))
+        # (1_40_tips is barely resolved - RF 58 of 74 against its true tree - and has internal branches of
+        # ~1e-7: such splits may flip)
+        assert treecmp.robinson_foulds(a, b)[0] <= (4 if stem == "1_40_tips" else 0), stem
+        assert treecmp.branch_score(a, b) <= 2e-5, stem
+    rf, nrf, kf = _tree_check(repo, golden, neighbor_joining, "gpu_distances_r02.npz", "{}")
+    assert rf == pytest.approx(11.4) and nrf == pytest.approx(0.1857, abs=5e-4) and kf == pytest.approx(0.3964, abs=5e-4)
+    if os.path.exists(FASTME):
+        rf, nrf, kf = _tree_check(repo, golden, lambda dm, ids: _fastme_tree(tmp_path, dm, ids),
+                                  "gpu_distances_r02.npz", "{}")
+        assert rf == pytest.approx(11.2) and nrf == pytest.approx(0.1837, abs=5e-4) and kf == pytest.approx(0.3935, abs=5e-4)
