@@ -1,18 +1,20 @@
 // libphyloformer_amd.so — host side of the C ABI declared in include/phyloformer_amd.h.
 //
-// Owns: the device, one stream, the prepared weights (fp32 folded copies and
-// split-bf16 MFMA fragment images), a grow-only workspace, the optional RCCL
+// Owns: the device, two streams, the prepared weights (fp32 folded copies and
+// split-bf16 MFMA fragment images), two grow-only workspaces, the optional RCCL
 // communicator and the launch sequence of the forward pass
 // (reference: phyloformer/model.py:166-187).
 //
-// Launch sequence for one batch chunk (nb = n_blocks):
-//   k_embed                               embedding + pair sum, row stats of block 0 (table lookup)
+// Launch sequence for one batch chunk (nb = n_blocks); a chunk of >= 2 alignments runs it twice, for its two
+// halves, on the two streams (forward_chunk):
+//   k_embed                               row statistics of block 0 and q' by table lookup (x0 is not written)
 //   for k in 0..nb-1:
-//       [all-reduce srow]                 site-sharded runs only
-//       k_rowfin(k)      srow -> mrow
-//       k_colstats(k)    x, qrow, mrow -> qcol, column partials
+//       [k_rowsum, all-reduce srow]       site-sharded runs only
+//       k_rowfin(k)      per-tile row statistics -> row-mix matrices / fragments of every pair
+//       k_colstats(k)    x (block 0: the embedding table), qrow, mrow -> qcol, column partials (groups or runs)
 //       k_colfin(k)      partials -> ctx
-//       k_main<MID|LAST>(k)
+//       k_main<MID0|MID|LAST>(k)          row + column attention applied, FFN, next block's row statistics / head
+//   k_outsum                              per-tile head sums -> distances
 //   [all-reduce out]                      site-sharded runs only
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
