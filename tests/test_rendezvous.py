@@ -88,3 +88,82 @@ def test_tcp_group_single_rank_is_trivial():
         assert g.allgather("x") == ["x"] and g.allreduce_max(3.0) == 3.0
         assert g.broadcast_bytes(b"a" * 128, 128) == b"a" * 128
         g.barrier()
+
+
+def _hub_worker(key, tmp, q):
+    sys.path.insert(0, REPO)
+    from phyloformer_amd.rendezvous import TcpGroup
+    try:
+        with TcpGroup(0, 2, key=key, directory=tmp, timeout=30) as g:
+            q.put(("hub", g.allgather("zero")))
+    except Exception as exc:  # noqa: BLE001
+        q.put(("hub", "EXC " + repr(exc)))
+
+
+def test_hub_survives_stray_and_hostile_clients(tmp_path):
+    """rank 0 must not unpickle, must not block on a silent client and must not die on garbage.
+    A silent client, a client with a wrong token and a client that sends a pickle are dropped; the real rank 1
+    then joins and the collective completes."""
+    import json
+    import pickle
+    import socket
+    import stat
+    import struct
+    import time
+    sys.path.insert(0, REPO)
+    from phyloformer_amd.rendezvous import TcpGroup
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "pf_test_" + uuid.uuid4().hex
+    hub = ctx.Process(target=_hub_worker, args=(key, str(tmp_path), q))
+    hub.start()
+    path = os.path.join(str(tmp_path), key + ".json")
+    for _ in range(400):
+        if os.path.exists(path):
+            break
+        time.sleep(0.05)
+    assert stat.S_IMODE(os.stat(path).st_mode) == 0o600, "the rendezvous file must not be world-readable"
+    with open(path) as fh:
+        info = json.load(fh)
+    assert len(info["token"]) == 32
+    silent = socket.create_connection(("127.0.0.1", info["port"]))          # says nothing
+    wrong = socket.create_connection(("127.0.0.1", info["port"]))
+    wrong.sendall(b"x" * 32 + struct.pack("<Q", 5) + b"hello")               # wrong token
+    evil = socket.create_connection(("127.0.0.1", info["port"]))
+    raw = pickle.dumps({"rank": 1, "world": 2})
+    evil.sendall(info["token"].encode() + struct.pack("<Q", len(raw)) + raw)  # right token, pickle instead of JSON
+    huge = socket.create_connection(("127.0.0.1", info["port"]))
+    huge.sendall(info["token"].encode() + struct.pack("<Q", 1 << 40))        # absurd length
+    t0 = time.monotonic()
+    with TcpGroup(1, 2, key=key, directory=str(tmp_path), timeout=30) as g:
+        assert g.allgather("one") == ["zero", "one"]
+    assert time.monotonic() - t0 < 20, "a silent client must not hold the hub for its whole timeout"
+    tag, got = q.get(timeout=30)
+    assert got == ["zero", "one"], got
+    hub.join(timeout=30)
+    assert hub.exitcode == 0
+    for s in (silent, wrong, evil, huge):
+        s.close()
+
+
+def test_messages_are_plain_values_only():
+    sys.path.insert(0, REPO)
+    from phyloformer_amd import rendezvous as rz
+    assert rz._decode(rz._encode([1, 2.5, "a", None, True, b"\x00\xff", (3, b"x")])) == \
+        [1, 2.5, "a", None, True, b"\x00\xff", [3, b"x"]]
+    with pytest.raises(TypeError):
+        rz._encode(object())
+    assert "pickle" not in open(rz.__file__).read().split('"""', 2)[2], "no pickle on the wire"
+
+
+def test_private_dir_is_0700_and_checked(tmp_path, monkeypatch):
+    import stat
+    import tempfile
+    sys.path.insert(0, REPO)
+    from phyloformer_amd import rendezvous as rz
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    d = rz.private_dir()
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    os.chmod(d, 0o755)
+    with pytest.raises(rz.RendezvousError):
+        rz.private_dir()

@@ -6,7 +6,10 @@
 // Variants: plain C++ loop (the production body of round 1) with 1 or 2 waves per SIMD, the two-tile asm stream
 // (one wave per SIMD) and the one-tile software-pipelined asm stream (two waves per SIMD).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <chrono>
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -265,14 +268,65 @@ void run(const char* name, const bf16x8* wimg, const float* consts, float* out, 
     (void)cyc;
 }
 
-int main() {
+// ---- energy mode: `ffn3_bench_<mode> energy [seconds]` -------------------------------------------
+// Runs one variant back to back for a few seconds and reads the socket energy counter
+// (rsmi_dev_energy_count_get, librocm_smi64 through dlopen: sysfs reads, no subprocess) before and after:
+// joules per 32-token tile, average watts and the effective shader clock under sustained load.
+struct Rsmi {
+    void* lib = nullptr;
+    int (*energy)(uint32_t, uint64_t*, float*, uint64_t*) = nullptr;
+    bool ok = false;
+    Rsmi() {
+        lib = dlopen("/opt/rocm/lib/librocm_smi64.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librocm_smi64.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { printf("energy: cannot load librocm_smi64: %s\n", dlerror()); return; }
+        auto init = reinterpret_cast<int (*)(uint64_t)>(dlsym(lib, "rsmi_init"));
+        energy = reinterpret_cast<int (*)(uint32_t, uint64_t*, float*, uint64_t*)>(dlsym(lib, "rsmi_dev_energy_count_get"));
+        if (!init || !energy || init(0) != 0) { printf("energy: rsmi_init failed\n"); return; }
+        ok = true;
+    }
+    double joules() {
+        uint64_t c = 0, ts = 0; float res = 0;
+        if (!ok || energy(0, &c, &res, &ts) != 0) return -1;
+        return (double)c * res * 1e-6;
+    }
+};
+
+template <typename Launch>
+void energy_run(Rsmi& smi, const char* name, double seconds, double tiles_per_launch, int waves_per_simd, Launch launch) {
+    launch();                                       // warm-up: clocks up, LDS image resident in L2
+    hipDeviceSynchronize();
+    const double j0 = smi.joules();
+    const auto t0 = std::chrono::steady_clock::now();
+    long n = 0;
+    double dt = 0;
+    do {
+        for (int i = 0; i < 8; ++i) launch();
+        hipDeviceSynchronize();
+        n += 8;
+        dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (dt < seconds);
+    const double j1 = smi.joules();
+    const double wc = mean_cycles();                // shader cycles of one wave for the last launch
+    const double tiles = tiles_per_launch * n;
+    const double per_launch_s = dt / n;
+    printf("energy %-22s %7.1f W  %8.3f uJ/tile  %6.2f us/tile/SIMD  %7.0f cycles/tile/SIMD  clock %.2f GHz  (%ld launches, %.2f s, %.1f J)\n",
+           name, (j1 - j0) / dt, (j1 - j0) / tiles * 1e6, dt * 1e6 * 1024.0 / tiles,
+           wc / (tiles_per_launch / 1024.0), wc / per_launch_s * 1e-9, n, dt, j1 - j0);
+    (void)waves_per_simd;
+}
+
+int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
-    const int iters = 64;
+    const bool energy = argc > 1 && std::strcmp(argv[1], "energy") == 0;
+    const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
+    const bool zero = getenv("PF_ZERO") != nullptr;      // all-zero weights: the data-dependent part of the power
+    const int iters = energy ? 2048 : 64;
     std::vector<uint16_t> img((size_t)FRAG_END * 8);
     for (size_t i = 0; i < img.size(); ++i) {
         // W ~ +-[0.03, 0.12], deterministic
         const uint32_t r = (uint32_t)(i * 2654435761u);
-        img[i] = (uint16_t)(0x3d00 + ((r >> 20) % 256) + ((r >> 9) & 1 ? 0x8000 : 0));
+        img[i] = zero ? 0 : (uint16_t)(0x3d00 + ((r >> 20) % 256) + ((r >> 9) & 1 ? 0x8000 : 0));
     }
     std::vector<float> cst(CONST_LEN);
     for (int i = 0; i < CONST_LEN; ++i) cst[i] = 0.05f * (float)((i * 37) % 21 - 10);
@@ -284,6 +338,28 @@ int main() {
     hipMalloc((void**)&g_cyc, 256 * 8);
     hipMemcpy(d_img, img.data(), img.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(d_c, cst.data(), cst.size() * 4, hipMemcpyHostToDevice);
+    if (energy) {
+        Rsmi smi;
+        if (!smi.ok) return 1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hid<M_HID2, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hid<M_PLAIN, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES);
+        {   // idle baseline
+            const double j0 = smi.joules();
+            const auto t0 = std::chrono::steady_clock::now();
+            hipDeviceSynchronize();
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) {}
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("energy idle                   %7.1f W\n", (smi.joules() - j0) / dt);
+        }
+        energy_run(smi, "asm two-tile 1w/SIMD", seconds, 256.0 * 4 * iters * 2, 1, [&] {
+            hipLaunchKernelGGL((k_hid<M_HID2, 256>), dim3(256), dim3(256), MAIN_LDS_BYTES, 0, d_img, d_c, d_out, (float*)nullptr, iters, g_cyc);
+        });
+        if (getenv("PF_PLAIN"))
+            energy_run(smi, "plain C++ 2w/SIMD", seconds, 256.0 * 8 * iters * 2, 2, [&] {
+                hipLaunchKernelGGL((k_hid<M_PLAIN, 512>), dim3(256), dim3(512), MAIN_LDS_BYTES, 0, d_img, d_c, d_out, (float*)nullptr, iters, g_cyc);
+            });
+        return 0;
+    }
     run<M_PLAIN, 256>("plain C++ 1w/SIMD", d_img, d_c, d_out, d_dump, iters);
     run<M_PLAIN, 512>("plain C++ 2w/SIMD", d_img, d_c, d_out, d_dump, iters);
     run<M_HID2, 256>("asm two-tile 1w/SIMD", d_img, d_c, d_out, d_dump, iters);

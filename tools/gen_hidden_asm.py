@@ -76,7 +76,8 @@ class Regs:
         return f"a[{lo}:{lo + n - 1}]"
 
 
-MODE = "base"      # experiment switch (tools/ffn3_bench.hip): base | nodot | nosplit | poly3 | movonly
+MODE = "base"      # experiment switch (tools/ffn3_bench.hip): base | nodot | nosplit | poly3 | movonly | fmaonly | mfmaonly
+NOLDS = False      # "<mode>+nolds": no fragment reads (the MFMAs reuse whatever the fragment registers hold)
 
 
 def schedule_gelu(R, y):
@@ -95,6 +96,8 @@ def schedule_gelu(R, y):
         return []
     if MODE == "movonly":
         return [f"v_mov_b32 v{R.tmp + (i % 16)}, v{ha + (i % 16)}" for i in range(160)]
+    if MODE == "fmaonly":      # the same 160 slots as plain fp32 FMAs (three register reads, no transcendental)
+        return [f"v_fma_f32 v{R.tmp + (i % 16)}, v{ha + (i % 16)}, v{R.c4}, v{R.tmp + ((i + 5) % 16)}" for i in range(160)]
     for r in range(16):
         x, p = f"v{ha + r}", f"v{R.tmp + r}"
         if MODE == "poly3":
@@ -187,6 +190,8 @@ def half_step(R, X, Y, g2, g1, gelu, w1_off, w2_off, b_off, load_bias_next, firs
     def frag_reads(buf, i, g2_, g1_, w1o, w2o):
         rd = []
         u, To = i >> 1, i & 1
+        if NOLDS:
+            return rd
         if g1_:
             rd.append(f"ds_read_b128 {R.at(F[buf] + 0, 4)}, v{R.aw1} offset:{w1o + i * 2048}")
             rd.append(f"ds_read_b128 {R.at(F[buf] + 4, 4)}, v{R.aw1} offset:{w1o + i * 2048 + 1024}")
@@ -374,6 +379,10 @@ def main():
     fill = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     if len(sys.argv) > 2:
         MODE = sys.argv[2]
+        if MODE.endswith("+nolds"):
+            global NOLDS
+            NOLDS = True
+            MODE = MODE[:-len("+nolds")]
     print("// GENERATED by tools/gen_hidden_asm.py - do not edit.  Hand-scheduled FFN hidden loop (gfx950).")
     print(f"// fillers per MFMA gap: {fill}")
     variants = (("PF_HID2", gen_two_tile), ("PF_HID1", gen_one_tile))
