@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+#define PF_ABI_VERSION 2
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -99,12 +99,8 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "debug_keep" int   1 = keep per-layer activations for pf_debug_read
  *   "force_rccl" int   1 = pf_comm_init creates a real RCCL communicator even for one rank (tests)
  *   "ws_limit_mb" int  workspace budget per batch chunk (default 24576)
- *   "colstats_mfma" int 1 = column statistics with the MFMA formulation (k_colstats2) instead of the VALU
- *                      kernel (k_colstats): a measured alternative that is not faster; cross-check only
  *   "colstats_fine" int k_colstats blocks per pair group (0), per run of a group (1) or chosen from the batch
  *                      size (-1, default): the same summation tree either way, so the same bits; tests/tools
- *   "main2"      int   1 = k_main2 (one wave per SIMD, two tiles in flight, hand-placed hidden loop) instead of
- *                      the two-waves-per-SIMD k_main; same results bit for bit, measured 4 % slower (default 0)
  *   "two_streams" int  0 = a batch runs on one stream; default 1: forwards of >= 2 alignments run as two
  *                      independent half-batches on two streams (same results bit for bit, a few % faster);
  *                      environment PF_TWO_STREAMS=0/1 sets the initial value (A/B runs of whole programs)
@@ -134,7 +130,8 @@ int pf_forward_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N
 /* Site-sharded forward: this rank holds sites [l_begin, l_end) of an alignment
  * with L_total sites.  idx: host uint8 [B][N][l_end - l_begin].  Every rank
  * receives the full result in out [B][P].  The row-attention statistics are all-reduced once per
- * block and the site sums once at the end (n_blocks + 1 collectives on the handle's stream).
+ * block and the site sums once at the end (n_blocks + 1 collectives; with B >= 2 and "overlap" = 1 the
+ * batch runs as two half-batches on two streams with one communicator each: 2 (n_blocks + 1) collectives).
  * Requires pf_comm_init when the communicator has more than one rank; a partial site range
  * (l_end - l_begin < L_total) on a handle without a communicator fails with PF_ESTATE instead of
  * returning partial sums. */
@@ -145,8 +142,13 @@ int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, i
 
 /* RCCL bootstrap (one process per GPU).  Rank 0 calls pf_comm_unique_id and
  * ships the PF_UNIQUE_ID_BYTES bytes to the other ranks by any means
- * (torch.distributed store, file, socket); every rank then calls pf_comm_init. */
-#define PF_UNIQUE_ID_BYTES 128
+ * (torch.distributed store, file, socket); every rank then calls pf_comm_init.
+ * The blob is opaque: two ncclUniqueIds, because pf_comm_init creates TWO communicators, one per
+ * stream of the handle - a site-sharded forward runs its two half-batches on two streams, and a
+ * communicator of its own per stream means RCCL never orders one half's all-reduce behind the
+ * other's.  pf_comm_init is collective (every rank, same order) and all-or-nothing: on failure the
+ * handle keeps no communicator and stays a working single-rank engine. */
+#define PF_UNIQUE_ID_BYTES 256
 int pf_comm_unique_id(void* id_out);
 int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t world_size);
 int pf_comm_destroy(pf_handle_t* h);
@@ -165,7 +167,8 @@ int pf_memcpy_d2h(pf_handle_t* h, void* dst, const void* src, size_t bytes);
 
 /* Per-kernel HIP-event timing ("profile" = 1).  Names: "embed", "rowfin",
  * "colstats", "colfin", "main", "allreduce", "mha_qkv", "mha_attn", "mha_out".  Totals accumulate
- * until reset. */
+ * until reset.  "collectives" returns the number of all-reduces issued since the last reset in
+ * *launches (counted always, no profiling option needed; *total_ms = 0). */
 int pf_profile_reset(pf_handle_t* h);
 int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double* total_ms);
 

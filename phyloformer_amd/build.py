@@ -18,7 +18,6 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphyloformer_amd.so")
 SOURCES = [os.path.join(CSRC, "pf_lib.hip"), os.path.join(CSRC, "pf_hostio.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "pf_device.hip.h"), os.path.join(CSRC, "pf_mha.hip.h"),
-                  os.path.join(CSRC, "pf_main2.hip.h"), os.path.join(CSRC, "pf_hidden_asm.inc"),
                   os.path.join(os.path.dirname(HERE), "include", "phyloformer_amd.h")]
 ARCH = "gfx950"
 

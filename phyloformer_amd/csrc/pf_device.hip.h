@@ -628,87 +628,6 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
                     if (ntask < task1) prefetch(nrow, ntile);
                     PF_TICK(2);
-#ifdef PF_LOOP_PIPE
-                    // Software pipeline over the hidden tiles with hand-placed program order: every group is one
-                    // MFMA - alternately GEMM1 of tile T+1 and GEMM2 of tile T-1, so consecutive MFMAs never
-                    // share an accumulator - followed by the GELU chain of ONE hidden value of tile T (or the
-                    // split of one value pair), closed by sched_barrier(0) so that hipcc keeps the order.
-                    {
-                        auto step = [&](f32x16& hn, const f32x16& hc, unsigned (&gch)[8], unsigned (&gcl)[8],
-                                        const unsigned (&gph)[8], const unsigned (&gpl)[8], lds_frag_t f1n, lds_f32_t bpn,
-                                        lds_frag_t f2p, const bool g1, const bool g2) {
-                            if (g1) load_acc_bias(hn, bpn);
-                            float gv[16];
-                            bf16x8 ah, al, wh, wl;
-#pragma unroll
-                            for (int i = 0; i < 24; ++i) {
-                                const int k = i >> 1;                    // MFMA index inside its GEMM (0..11)
-                                const int s4 = k / 3, pass = k % 3;
-                                if ((i & 1) == 0) {
-                                    if (g1) {
-                                        if (pass == 0) { ah = f1n[s4 * 128]; al = f1n[s4 * 128 + 64]; }
-                                        hn = PF_MFMA(pass == 2 ? al : ah, pass == 0 ? xb_lo[s4] : xb_hi[s4], hn);
-                                    }
-                                } else if (g2) {
-                                    const int u = s4 >> 1, To = s4 & 1;
-                                    if (pass == 0) { wh = f2p[(To * 32 + u * 2) * 64]; wl = f2p[(To * 32 + u * 2) * 64 + 64]; }
-                                    bf16x8 ghi, glo;
-                                    {
-                                        u32x4 qh = {gph[4 * u], gph[4 * u + 1], gph[4 * u + 2], gph[4 * u + 3]};
-                                        u32x4 ql = {gpl[4 * u], gpl[4 * u + 1], gpl[4 * u + 2], gpl[4 * u + 3]};
-                                        ghi = __builtin_bit_cast(bf16x8, qh);
-                                        glo = __builtin_bit_cast(bf16x8, ql);
-                                    }
-                                    // (hi,lo) (hi,hi) (lo,hi) for To = 0, reversed for To = 1: same order as mfma3()
-                                    const int ps = To ? 2 - pass : pass;
-                                    oa[To] = PF_MFMA(ps == 2 ? wl : wh, ps == 0 ? glo : ghi, oa[To]);
-                                }
-                                if (i < 16) gv[i] = gelu_scaled(hc[i]);
-                                else split_pair(gv[2 * (i - 16)], gv[2 * (i - 16) + 1], gch[i - 16], gcl[i - 16]);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        };
-                        f32x16 hA, hB;
-                        unsigned gAh[8], gAl[8], gBh[8], gBl[8];
-                        {   // prologue: GEMM1 of hidden tile 0
-                            lds_frag_t f1 = w1p; lds_f32_t bp = lch + CONST_B1;
-                            PF_OPAQUE(f1); PF_OPAQUE(bp);
-                            load_acc_bias(hA, bp);
-#pragma unroll
-                            for (int s4 = 0; s4 < 4; ++s4) {
-                                const bf16x8 fh = f1[s4 * 128], fl = f1[s4 * 128 + 64];
-                                mfma3(hA, fh, fl, xb_hi[s4], xb_lo[s4]);
-                            }
-                        }
-                        {   // T = 0: GEMM1(1) beside gelu(0)
-                            lds_frag_t f1 = w1p + 512; lds_f32_t bp = lch + CONST_B1 + 32;
-                            PF_OPAQUE(f1); PF_OPAQUE(bp);
-                            step(hB, hA, gAh, gAl, gAh, gAl, f1, bp, f1, true, false);
-                        }
-#pragma unroll 1
-                        for (int j = 0; j < 3; ++j) {
-                            lds_frag_t f1 = w1p + (2 * j + 2) * 512;      // W1 of tile 2j+2 (and 2j+3 at +512)
-                            lds_frag_t f2 = w2p + (2 * j) * 256;          // W2 of tile 2j (and 2j+1 at +256)
-                            lds_f32_t bp = lch + CONST_B1 + 32 * (2 * j + 2);
-                            PF_OPAQUE(f1); PF_OPAQUE(f2); PF_OPAQUE(bp);
-                            step(hA, hB, gBh, gBl, gAh, gAl, f1, bp, f2, true, true);                   // T = 2j+1
-                            step(hB, hA, gAh, gAl, gBh, gBl, f1 + 512, bp + 32, f2 + 256, true, true);   // T = 2j+2
-                        }
-                        {   // T = 7: GEMM2(6) beside gelu(7); then GEMM2(7)
-                            lds_frag_t f2 = w2p + 6 * 256;
-                            PF_OPAQUE(f2);
-                            step(hA, hB, gBh, gBl, gAh, gAl, f2, lch, f2, false, true);
-#pragma unroll
-                            for (int st = 0; st < 4; ++st) {
-                                const int u = st >> 1, To = st & 1;
-                                const bf16x8 fh = f2[256 + (To * 32 + u * 2) * 64], fl = f2[256 + (To * 32 + u * 2) * 64 + 64];
-                                u32x4 qh = {gBh[4 * u], gBh[4 * u + 1], gBh[4 * u + 2], gBh[4 * u + 3]};
-                                u32x4 ql = {gBl[4 * u], gBl[4 * u + 1], gBl[4 * u + 2], gBl[4 * u + 3]};
-                                mfma3(oa[To], fh, fl, __builtin_bit_cast(bf16x8, qh), __builtin_bit_cast(bf16x8, ql), To == 1);
-                            }
-                        }
-                    }
-#else
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
                         f32x16 ha;
@@ -745,7 +664,6 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                             fh = nh; fl = nl;
                         }
                     }
-#endif
                     PF_TICK(3);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) x[j] = oa[j >> 4][j & 15];
@@ -1340,222 +1258,6 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     }
 }
 
-
-// ---- column statistics on the matrix cores -------------------------------------------------------------
-// One wave = one task (alignment b, chunk of 32 sites, pair group g): it walks the group's pairs with the
-// 32 tokens of a pair row in k_main's layout (lane (t, h) owns 32 channels of site t), so the two dense
-// contractions per token run on MFMA exactly as in k_main - the row-attention apply (K-padded product with
-// the pair's row-mix fragments) and the folded q/k projection (8 of 32 rows) - and only LayerNorm, the
-// activation and Z~[h][c] += k'[h] x~[c] (128 FMAs per lane and pair, the accumulators live in registers
-// for the whole walk) are vector work: 13 instead of 27.5 VALU instructions per token.  The next pair's
-// token rows reach LDS with global_load_lds (double-buffered, no staging registers); each wave reads back
-// only what it loaded itself, so there is no barrier in the loop.
-struct ColStats2Args {
-    const float* x;        // [B][P][Lloc][64]
-    const float* qrow;     // [B][P][Lloc][4]
-    const bf16x8* mfrag;   // [B][P][2 To][2 hi/lo][32]
-    float* qcol;           // [B][P][Lloc][4]  out (+ 32-token trash area)
-    float* part;           // [B][G][Lloc][4*64 + 8]  out: Z~[h][c] | S_q[4] | S_k[4]
-    const bf16x8* wqk;     // folded column q/k rows as MFMA A fragments: [4 s][2 hi/lo][2 kgrp][8 rows]
-    const float* bqk;      // [8]
-    int B, P, Lloc, G, nchunks;
-    size_t trash_tok;
-    unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
-    int ablate;                 // perf experiments only (results invalid): 1 = stage only the first tile, 2 = no math
-};
-constexpr int CS2_THREADS = 512;                       // 8 waves: two per SIMD
-constexpr int CS2_XBUF = 32 * 64 * 4;                  // one tile of x: 8 KB
-constexpr int CS2_MBUF = 128 * 16;                     // one pair's row-mix fragments: 2 KB
-constexpr int CS2_WAVE_LDS = 2 * CS2_XBUF + CS2_MBUF;  // per wave: x double buffer + fragments
-constexpr int CS2_LDS_BYTES = (CS2_THREADS / 64) * CS2_WAVE_LDS + 128 * 16 + 64;
-
-__global__ void __launch_bounds__(CS2_THREADS, 2) k_colstats2(ColStats2Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = lane & 31, h = lane >> 5;
-    unsigned char* xbuf = csm + (size_t)wave * CS2_WAVE_LDS;
-    unsigned char* mbuf = xbuf + 2 * CS2_XBUF;
-    bf16x8* qkl = reinterpret_cast<bf16x8*>(csm + (CS2_THREADS / 64) * CS2_WAVE_LDS);
-    float* bql = reinterpret_cast<float*>(qkl + 128);
-    for (int i = threadIdx.x; i < 128; i += CS2_THREADS) qkl[i] = a.wqk[i];
-    if (threadIdx.x < 8) bql[threadIdx.x] = a.bqk[threadIdx.x];
-    __syncthreads();
-
-    const long ntasks = (long)a.B * a.nchunks * a.G;
-    const long task = (long)blockIdx.x * (CS2_THREADS / 64) + wave;
-    if (task >= ntasks) return;
-    // neighbouring waves take neighbouring site chunks of the same pair group: they walk the same pairs
-    // and share the row-mix fragments in L2
-    const int chunk = (int)(task % a.nchunks);
-    const int g = (int)((task / a.nchunks) % a.G);
-    const int b = (int)(task / ((long)a.nchunks * a.G));
-    const int l = chunk * 32 + t;
-    const bool valid = l < a.Lloc;
-    const int lcl = valid ? l : a.Lloc - 1;
-    const int per = (a.P + a.G - 1) / a.G;
-    const int p0 = g * per, p1 = min(a.P, p0 + per);
-    if (p0 >= p1) return;     // (cannot happen with colstats_groups(), which keeps per * (G - 1) < P)
-
-    lds_frag_t qkp = (lds_frag_t)(qkl) + h * 8 + (t & 7);
-    PF_OPAQUE(qkp);
-    float bq[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bq[r] = bql[4 * h + r];
-
-    float z[4][32], sq[4], sk[4];
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
-        sq[hh] = 0.f; sk[hh] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) z[hh][j] = 0.f;
-    }
-    const float vm = valid ? 1.f : 0.f;
-
-    // Staging of one 8 KB tile (32 tokens x 256 B, contiguous in HBM).  DMA instruction k moves the k-th
-    // KB: lane i fetches one 16-byte piece of tokens 4k .. 4k+3 and it lands at LDS k*1024 + i*16, so every
-    // instruction reads 1 KB of consecutive addresses (a per-token 32-byte-per-lane pattern reaches only half
-    // the bandwidth).  Which piece a lane fetches is chosen so that the later ds_read_b128 of lane (t, h) -
-    // piece c16 = 2 g8 + h of token t - is bank-conflict free: piece c16 of token tt of KB k sits in slot
-    //   tt * 16 + ((c16 + 4 (k & 3) + tt) & 15),
-    // which gives the 16 lanes of every ds_read_b128 service group 16 different bank quads.
-    const size_t pair_stride = (size_t)a.Lloc * 64;
-    const float* xb0 = a.x + (size_t)b * a.P * a.Lloc * 64;
-    int src_off[8];                       // per DMA instruction: float offset of this lane's piece inside a pair row
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int tt = lane >> 4;
-        const int c16 = ((lane & 15) - 4 * (k & 3) - tt) & 15;
-        const int site = min(chunk * 32 + 4 * k + tt, a.Lloc - 1);      // tiles past the row end re-read its last site
-        src_off[k] = site * 64 + c16 * 4;
-    }
-    int rd_off[8];                        // per piece g8: byte offset of lane (t, h)'s read inside a buffer
-#pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8)
-        rd_off[g8] = (t >> 2) * 1024 + ((t & 3) * 16 + ((2 * g8 + h + 4 * ((t >> 2) & 3) + (t & 3)) & 15)) * 16;
-    auto stage = [&](int p, int buf) {
-        const float* src = xb0 + (size_t)p * pair_stride;
-        unsigned char* dst = xbuf + (size_t)buf * CS2_XBUF;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4*>(src + src_off[k]), dst + k * 1024, 16, 0, 0);
-    };
-    // the pair's row-mix fragments (2 KB, [2 To][2 hi/lo][32 lanes]) go through LDS too, single-buffered: the
-    // next pair's are requested once this pair's have been read into registers
-    auto stage_frags = [&](int p) {
-        const bf16x8* mf = a.mfrag + ((size_t)b * a.P + p) * 128 + lane;
-        __builtin_amdgcn_global_load_lds(mf, mbuf, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(mf + 64, mbuf + 1024, 16, 0, 0);
-    };
-    f32x4 nqr;
-    auto fetch = [&](int p) {
-        nqr = *reinterpret_cast<const f32x4*>(a.qrow + (((size_t)b * a.P + p) * a.Lloc + lcl) * 4);
-    };
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define PF_TICK(k) do { if (a.prof) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; } } while (0)
-    stage(p0, 0);
-    stage_frags(p0);
-    fetch(p0);
-    int buf = 0;
-    if (a.prof) tprev = __builtin_amdgcn_s_memtime();
-    for (int p = p0; p < p1; ++p, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this pair's tile and fragments have landed in LDS
-        PF_TICK(0);
-        const f32x4 qr = nqr;
-        bf16x8 mfr[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mfr[q] = *reinterpret_cast<const bf16x8*>(mbuf + (q * 32 + t) * 16);
-        const int pn = min(p + 1, p1 - 1);
-        if (!(a.ablate & 1)) stage(pn, buf ^ 1);                // next pair: lands during this one's math
-        fetch(pn);
-        if (a.ablate & 2) { sq[0] += qr[0]; continue; }
-        // x' = x + row attention of this block (row out_proj bias in K slot 4; slot 5, the column bias, off)
-        f32x16 ya[2];
-        {
-            const unsigned char* xl = xbuf + (size_t)buf * CS2_XBUF;
-#pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(xl + rd_off[g8]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ya[g8 >> 2][4 * (g8 & 3) + i] = u[i];
-            }
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
-            v[4] = (h == 0) ? 1.f : 0.f;
-            v[5] = v[6] = v[7] = 0.f;
-            bf16x8 qb_hi, qb_lo;
-            split8(v, qb_hi, qb_lo);
-#pragma unroll
-            for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo, To == 1);
-            stage_frags(pn);                                    // mfr is in registers: its LDS slot is free
-        }
-        PF_TICK(1);
-        float xn[32];
-        {
-            float xr[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) xr[j] = ya[j >> 4][j & 15];
-            ln_pair(xr, xn);
-        }
-        PF_TICK(2);
-        // folded q (rows 0-3) and k (rows 4-7) projections: 8 of the 32 output rows are used
-        f32x16 va;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 xb_hi, xb_lo;
-            split8(&xn[8 * s], xb_hi, xb_lo);
-            const bf16x8 q_hi = qkp[(s * 2) * 16], q_lo = qkp[(s * 2 + 1) * 16];
-            if (s == 0) mfma3_zero(va, q_hi, q_lo, xb_hi, xb_lo);
-            else mfma3(va, q_hi, q_lo, xb_hi, xb_lo);
-        }
-        float qk[4], ot[4], qn[4], kn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) qk[i] = elu1_fast(va[i] + bq[i]);
-        PF_TICK(3);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ot[i] = pair_other(qk[i], h);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            qn[i] = h ? ot[i] : qk[i];
-            kn[i] = (h ? qk[i] : ot[i]) * vm;
-            sq[i] = fmaf(vm, qn[i], sq[i]);
-            sk[i] += kn[i];
-        }
-        {
-            // branch-free store (both halves write the same 16 bytes; lanes past the end hit the trash area)
-            const size_t stok = valid ? ((size_t)b * a.P + p) * a.Lloc + l : a.trash_tok + t;
-            const f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
-            *reinterpret_cast<f32x4*>(a.qcol + stok * 4) = qs;
-        }
-        PF_TICK(4);
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-            for (int j = 0; j < 32; ++j) z[hh][j] = fmaf(kn[hh], xn[j], z[hh][j]);
-        PF_TICK(5);
-    }
-    if (a.prof && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, tacc[k]);
-    }
-#undef PF_TICK
-    if (valid) {
-        float* out = a.part + (((size_t)b * a.G + g) * a.Lloc + l) * CPART;
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {
-                const f32x4 u = {z[hh][4 * g8], z[hh][4 * g8 + 1], z[hh][4 * g8 + 2], z[hh][4 * g8 + 3]};
-                *reinterpret_cast<f32x4*>(out + hh * 64 + 8 * g8 + 4 * h) = u;
-            }
-        if (h == 0) {
-            const f32x4 u = {sq[0], sq[1], sq[2], sq[3]}, w = {sk[0], sk[1], sk[2], sk[3]};
-            *reinterpret_cast<f32x4*>(out + 256) = u;
-            *reinterpret_cast<f32x4*>(out + 260) = w;
-        }
-    }
-}
 
 // ---- column finalisation: partials -> ctx --------------------------------------------------
 struct ColFinArgs {

@@ -26,12 +26,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/phyloformer_amd.h"
 #include "pf_device.hip.h"
-#include "pf_main2.hip.h"
 #include "pf_mha.hip.h"
 
 using namespace pfk;
@@ -41,7 +41,7 @@ namespace {
 thread_local std::string g_create_error;
 
 // ---- RCCL, resolved lazily so the library loads without it --------------------------------
-struct PfNcclId { char internal[PF_UNIQUE_ID_BYTES]; };
+struct PfNcclId { char internal[128]; };     // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)
 struct RcclApi {
     void* lib = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
@@ -50,16 +50,17 @@ struct RcclApi {
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
+// The only process-global mutable state of the library: resolved once (std::call_once), read-only afterwards.
 RcclApi g_rccl;
-
 std::string g_rccl_path;
 int g_rccl_version = 0;
+std::once_flag g_rccl_once;
+std::string g_rccl_err;     // why the one attempt failed (empty = loaded)
 
 // Resolution order is fixed so that the library does not depend on what else the process has mapped
 // (a Python process that imported torch carries torch's own bundled librccl / HIP runtime):
 // $PF_RCCL_LIB, then the ROCm installation this library was built against, then the loader's search path.
-bool load_rccl(std::string& err) {
-    if (g_rccl.lib) return true;
+bool load_rccl_once(std::string& err) {
     std::vector<std::string> names;
     if (const char* env = std::getenv("PF_RCCL_LIB")) names.push_back(env);
     else {
@@ -102,6 +103,12 @@ bool load_rccl(std::string& err) {
     if (auto getv = reinterpret_cast<int (*)(int*)>(dlsym(lib, "ncclGetVersion"))) getv(&g_rccl_version);
     g_rccl.lib = lib;
     return true;
+}
+bool load_rccl(std::string& err) {
+    std::call_once(g_rccl_once, [] { if (!load_rccl_once(g_rccl_err) && g_rccl_err.empty()) g_rccl_err = "librccl unavailable"; });
+    if (g_rccl.lib) return true;
+    err = g_rccl_err;
+    return false;
 }
 constexpr int NCCL_FLOAT = 7, NCCL_SUM = 0;
 
@@ -203,7 +210,6 @@ struct BlockDev {
     float* row_bo = nullptr;   // [64]
     float* col_bo = nullptr;   // [64] column out_proj bias (rides in the row-mix fragments, k_rowfin)
     float* col_wqk = nullptr;  // [8][64]
-    float* col_qkfrag = nullptr;  // the same rows as MFMA A fragments (128 x 16 bytes, k_colstats2)
     float* col_bqk = nullptr;  // [8]
     float* col_wvT = nullptr;  // [64][64]
     float* col_bv = nullptr;   // [64]
@@ -238,11 +244,8 @@ struct pf_handle {
     float* table = nullptr;       // [22][64]
     float* pair_table = nullptr;  // [484][72] block-0 row-attention contributions per residue pair (k_embed)
     bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
-    bool colstats_mfma = false;   // option "colstats_mfma": k_colstats2 (MFMA formulation) instead of k_colstats
     int colstats_fine = -1;       // option "colstats_fine": k_colstats blocks per run (1) / per group (0) / by batch (-1)
     bool materialize_x0 = false;  // option "materialize_x0": k_embed writes x0 and block 0 reads it (round-1 path)
-    bool main2 = false;           // option "main2": k_main2 (one wave per SIMD, two tiles, hand-placed hidden loop);
-                                  // bit-identical to k_main but 4 % slower, so off by default
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
     float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
     std::vector<BlockDev> blk;
@@ -260,9 +263,11 @@ struct pf_handle {
     int reserve_cus = 8;          // option "reserve_cus": CUs the persistent kernels leave to RCCL then
     uint8_t* d_idx = nullptr; size_t d_idx_bytes = 0;
     float* d_out = nullptr; size_t d_out_bytes = 0;
-    // comm
-    void* comm = nullptr;
+    // comm: one RCCL communicator per stream (comm[1] serves stream2), created together by pf_comm_init, so that
+    // RCCL never has to order one half-batch's collectives behind the other's with an implicit cross-stream wait
+    void* comm[2] = {nullptr, nullptr};
     int rank = 0, world = 1;
+    int64_t coll_calls = 0;      // collectives issued since the last pf_profile_reset ("collectives")
     bool sharded_call = false;   // set by pf_forward_sharded* for the duration of the call
     bool reducing = false;       // this forward issues collectives (persistent kernels leave reserve_cus CUs free)
     bool two_streams = true;     // option "two_streams": forwards of >= 2 alignments run as two free-running half-batches
@@ -448,11 +453,6 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         std::copy(cwk.begin(), cwk.end(), wqk.begin() + 4 * E);
         for (int i = 0; i < 4; ++i) { bqk[i] = cbq[i]; bqk[4 + i] = cbk[i]; }
         if ((rc = upload(h, wqk, &d.col_wqk))) return rc;
-        {
-            std::vector<uint16_t> qkf((size_t)128 * 8);
-            pack_qk_frags(cwq.data(), cwk.data(), qkf.data());
-            if ((rc = upload(h, qkf, &d.col_qkfrag))) return rc;
-        }
         if ((rc = upload(h, bqk, &d.col_bqk))) return rc;
         std::vector<float> wvT((size_t)E * E);
         for (int hd = 0; hd < E; ++hd)
@@ -553,7 +553,7 @@ void colstats_plan(const pf_handle* h, int B, int P, int Lloc, Workspace* w) {
     // by groups once they fill the chip's 512 resident blocks (2 per CU), by runs below that
     const long group_blocks = (long)B * ((Lloc + 31) / 32) * w->G;
     const bool auto_fine = w->S > 1 && group_blocks < 512;
-    w->fine = h->colstats_mfma ? 0 : h->colstats_fine < 0 ? (int)auto_fine : (h->colstats_fine && w->S > 1);
+    w->fine = h->colstats_fine < 0 ? (int)auto_fine : (h->colstats_fine && w->S > 1);
 }
 
 size_t workspace_bytes(int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) {
@@ -639,10 +639,12 @@ int save_tap(pf_handle* h, const std::string& name, const float* dptr, size_t n)
 // that carries a communicator (alignment-level data parallelism) must not reduce across ranks.
 int allreduce(pf_handle* h, float* buf, size_t count) {
     if (!h->sharded_call) return PF_OK;
-    if (h->world <= 1 && !h->comm) return PF_OK;
-    if (!h->comm) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
+    if (h->world <= 1 && !h->comm[0]) return PF_OK;
+    if (!h->comm[0]) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
     ProfScope ps(h, K_ALLREDUCE);
-    int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, h->comm, h->cur);
+    void* comm = h->comm[(h->cur == h->stream2 && h->stream2) ? 1 : 0];    // the stream's own communicator
+    ++h->coll_calls;
+    int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, comm, h->cur);
     if (rc != 0)
         return fail(h, PF_ERCCL, "ncclAllReduce failed: %s",
                     g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
@@ -650,32 +652,7 @@ int allreduce(pf_handle* h, float* buf, size_t count) {
 }
 
 template <int MODE>
-int launch_main2(pf_handle* h, const MainArgs& a, int kid) {
-    static bool attr_set[16] = {false};
-    if (!attr_set[h->device & 15]) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_main2<MODE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES));
-        attr_set[h->device & 15] = true;
-    }
-    const long ntasks = (long)a.B * a.P * ((a.Lloc + 31) / 32);      // tiles; a wave takes them two at a time
-    const int cus = std::max(1, h->prop.multiProcessorCount - (h->reducing ? h->reserve_cus : 0));
-    const int grid = (int)std::max<long>(1, std::min<long>(cus, (ntasks + 2 * MAIN2_WAVES - 1) / (2 * MAIN2_WAVES)));
-    ProfScope ps(h, kid);
-    hipLaunchKernelGGL(k_main2<MODE>, dim3(grid), dim3(MAIN2_THREADS), MAIN_LDS_BYTES, h->cur, a);
-    HIPCHK(h, hipGetLastError());
-    return PF_OK;
-}
-
-template <int MODE>
 int launch_main(pf_handle* h, const MainArgs& a, int kid) {
-    if (h->main2 && MODE != MODE_FIRST && !(h->ablate))
-        return launch_main2<MODE == MODE_FIRST ? MODE_MID : MODE>(h, a, kid);
-    static bool attr_set[16] = {false};
-    if (!attr_set[h->device & 15]) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_main<MODE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS_BYTES));
-        attr_set[h->device & 15] = true;
-    }
     const long ntasks = (long)a.B * a.P * ((a.Lloc + 31) / 32);      // one work item per 32-site tile
     const int cus = std::max(1, h->prop.multiProcessorCount - (h->reducing ? h->reserve_cus : 0));
     const int grid = (int)std::max<long>(1, std::min<long>(cus, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
@@ -701,15 +678,15 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
     m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.trash_tok = (size_t)r.B * r.P * r.Lloc;
-    m.ablate = h->ablate >= 64 ? 0 : h->ablate;
-    m.prof = h->ablate == 64 ? nullptr : h->phase_prof;   // ablate = 64: the phase counters belong to k_colstats2
+    m.ablate = h->ablate;
+    m.prof = h->phase_prof;
     return m;
 }
 
 // Block 0's consumers (k_colstats, k_main) form x0 = T[a_i] + T[a_j] themselves unless the round-1 path is
 // requested; the MFMA cross-check kernels and single-block models keep the materialised x0.
 bool x0_on_the_fly(const pf_handle* h) {
-    return !h->materialize_x0 && !h->embed_mfma && !h->colstats_mfma && h->n_blocks > 1;
+    return !h->materialize_x0 && !h->embed_mfma && h->n_blocks > 1;
 }
 
 // embedding + pair expansion + row statistics of block 0
@@ -722,12 +699,6 @@ int phase_first(pf_handle* h, const ShardRun& r) {
         rc = launch_main<MODE_FIRST>(h, m, K_EMBED);
         if (rc) return rc;
     } else {
-        static bool attr_set[16] = {false};
-        if (!attr_set[h->device & 15]) {
-            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, EMBED_LDS_BYTES));
-            attr_set[h->device & 15] = true;
-        }
         // x0 is written only for those who read it: the round-1 consumers or the "x0" debug tap
         float* x0 = (x0_on_the_fly(h) && !h->debug_keep) ? nullptr : r.w.x;
         EmbedArgs e{r.d_idx, h->pair_i, h->pair_j, h->pair_table, h->table, x0, r.w.qrow, r.w.srow,
@@ -786,7 +757,7 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         if ((rc = save_tap(h, "srow" + std::to_string(k), rs.p, (size_t)B * P * SROW))) return rc;
     }
     {
-        RowFinArgs a{rs.p, (h->debug_keep || !h->colstats_mfma) ? w.mrow : nullptr, reinterpret_cast<bf16x8*>(w.mfrag),
+        RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag),
                      d.row_woT, d.row_bv, d.row_bo, d.col_bo,
                      B * P, rs.nparts, (float)r.L_total};
         ProfScope ps(h, K_ROWFIN);
@@ -794,34 +765,14 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         HIPCHK(h, hipGetLastError());
     }
     {
-        if (!h->colstats_mfma) {
-            ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
-                           w.sub, w.S, w.fine, h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
-            ProfScope ps(h, K_COLSTATS);
-            const unsigned nblk = (unsigned)(B * a.nchunks * w.nparts());
-            if (k == 0 && x0_on_the_fly(h))
-                hipLaunchKernelGGL(k_colstats<true>, dim3(nblk), dim3(256), 0, h->cur, a);
-            else
-                hipLaunchKernelGGL(k_colstats<false>, dim3(nblk), dim3(256), 0, h->cur, a);
-        } else {
-            // experiment (tools/colstats_compare.py): both contractions on MFMA, 13 instead of 27.5 VALU
-            // instructions per token, but no faster (0.96 vs 0.91 ms at batch 16, 0.145 vs 0.067 ms at batch 1)
-            static bool attr_set[16] = {false};
-            if (!attr_set[h->device & 15]) {
-                HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colstats2),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, CS2_LDS_BYTES));
-                attr_set[h->device & 15] = true;
-            }
-            ColStats2Args a{w.x, w.qrow, reinterpret_cast<const bf16x8*>(w.mfrag), w.qcol, w.part,
-                            reinterpret_cast<const bf16x8*>(d.col_qkfrag), d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
-                            (size_t)B * P * Lloc, h->ablate == 64 ? h->phase_prof : nullptr,
-                            h->ablate >= 128 ? (h->ablate >> 7) : 0};
-            const long ntasks = (long)B * a.nchunks * w.G;
-            const int wpb = CS2_THREADS / 64;
-            ProfScope ps(h, K_COLSTATS);
-            hipLaunchKernelGGL(k_colstats2, dim3((unsigned)((ntasks + wpb - 1) / wpb)), dim3(CS2_THREADS), CS2_LDS_BYTES,
-                               h->cur, a);
-        }
+        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
+                       w.sub, w.S, w.fine, h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
+        ProfScope ps(h, K_COLSTATS);
+        const unsigned nblk = (unsigned)(B * a.nchunks * w.nparts());
+        if (k == 0 && x0_on_the_fly(h))
+            hipLaunchKernelGGL(k_colstats<true>, dim3(nblk), dim3(256), 0, h->cur, a);
+        else
+            hipLaunchKernelGGL(k_colstats<false>, dim3(nblk), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     {
@@ -852,14 +803,14 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
 
 // one batch chunk, everything resident on the device
 // Does this forward issue collectives?  Only the site-sharded entry points on a handle with a communicator.
-bool reduces_now(const pf_handle* h) { return h->sharded_call && (h->world > 1 || h->comm); }
+bool reduces_now(const pf_handle* h) { return h->sharded_call && (h->world > 1 || h->comm[0]); }
 
 // How a chunk of B alignments is cut for the overlapped schedule: two halves when collectives run.  Every
 // rank must cut identically (one all-reduce sequence per half), so this depends on B and the options only.
 int halves_of(const pf_handle* h, int B) {
-    if (B < 2) return 1;
-    if (reduces_now(h)) return h->overlap ? 2 : 1;
-    return (h->two_streams && !h->debug_keep) ? 2 : 1;   // (debug taps are kept per name: one half only)
+    if (B < 2 || h->debug_keep) return 1;       // debug taps are kept per name: the whole chunk in one piece
+    if (reduces_now(h)) return h->overlap ? 2 : 1;   // (every rank sets the same options, so all cut alike)
+    return h->two_streams ? 2 : 1;
 }
 
 int ensure_second_stream(pf_handle* h) {
@@ -946,47 +897,96 @@ int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
     return PF_OK;
 }
 
-int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
+// Alignments per chunk under the workspace budget ("ws_limit_mb").  A chunk of cb alignments lives in `ws`
+// (ceil(cb / 2) alignments when it runs as two halves, else all cb) plus `ws2` (floor(cb / 2)); the per-alignment
+// size uses the column-statistics plan that will really be used (run-sized blocks can mean hundreds of partial
+// buffers per alignment, not the 32 of a whole-group walk).  Every rank derives the same number: it depends on
+// the shape, the options and the largest shard only.
+size_t chunk_bytes(const pf_handle* h, int cb, int P, int Lloc) {
     size_t off[WS_BUFS];
-    const size_t per = workspace_bytes(1, P, Lloc, 32, off);
-    int64_t nb = h->ws_limit_bytes / (int64_t)std::max<size_t>(per, 1);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(B, nb));
+    const int nh = halves_of(h, cb);
+    const int b0 = nh == 2 ? (cb + 1) / 2 : cb, b1 = nh == 2 ? cb / 2 : 0;
+    size_t total = 0;
+    for (int nb : {b0, b1}) {
+        if (nb < 1) continue;
+        Workspace w;
+        colstats_plan(h, nb, P, Lloc, &w);
+        total += workspace_bytes(nb, P, Lloc, w.nparts(), off);
+    }
+    return total;
+}
+
+int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
+    if (B <= 1 || chunk_bytes(h, B, P, Lloc) <= (size_t)h->ws_limit_bytes) return std::max(B, 1);
+    int lo = 1, hi = B;                     // largest cb in [1, B) that fits (cb = 1 always runs)
+    while (hi - lo > 1) {
+        const int mid = lo + (hi - lo) / 2;
+        if (chunk_bytes(h, mid, P, Lloc) <= (size_t)h->ws_limit_bytes) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Grow-only workspaces that no longer fit the budget together are released before a chunk is laid out
+// (a one-stream call may have left `ws` sized for a whole chunk that now runs as two halves).
+int trim_workspaces(pf_handle* h, size_t need_total) {
+    if (h->ws_bytes + h->ws2_bytes <= std::max(need_total, (size_t)h->ws_limit_bytes)) return PF_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+    if (h->ws) { hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
+    if (h->ws2) { hipFree(h->ws2); h->ws2 = nullptr; h->ws2_bytes = 0; }
+    return PF_OK;
 }
 
 int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_begin, int l_end,
                         int L_total, float* d_out) {
     const int Lloc = l_end - l_begin;
-    if (h && h->sharded_call && Lloc < L_total && !h->comm)
+    if (h && h->sharded_call && Lloc < L_total && !h->comm[0])
         // a partial site range without a communicator would return partial sums divided by L_total
         return fail(h, PF_ESTATE, "site range [%d, %d) of %d needs a communicator (pf_comm_init) to be reduced",
                     l_begin, l_end, L_total);
     if (h && Lloc == 0 && h->world > 1 && B >= 1 && N >= 2 && L_total >= 1) {
-        // a rank that owns no sites (L_total < world) still joins every collective with zeros: the same
-        // chunks, the same halves and the same counts as its peers issue (forward_chunk)
+        // A rank that owns no sites (L_total < world) still joins every collective with zeros: the same
+        // chunks, the same halves on the same two streams / communicators and the same counts as its peers
+        // issue (forward_chunk).
         HIPCHK(h, hipSetDevice(h->device));
         const int P0 = N * (N - 1) / 2;
         const int cb0 = chunk_batch(h, B, P0, (L_total + h->world - 1) / h->world);
+        h->reducing = true;
+        auto finish0 = [&](int code) { h->cur = h->stream; h->reducing = false; return code; };
         for (int b0 = 0; b0 < B; b0 += cb0) {
             const int nb0 = std::min(cb0, B - b0);
             Workspace w0;
             int rc0 = ensure_workspace(h, nb0, P0, 1, &w0);
-            if (rc0) return rc0;
+            if (rc0) return finish0(rc0);
             const int nh = halves_of(h, nb0);
             const int hb[2] = {nh == 2 ? (nb0 + 1) / 2 : nb0, nh == 2 ? nb0 / 2 : 0};
-            HIPCHK(h, hipMemsetAsync(d_out + (size_t)b0 * P0, 0, (size_t)nb0 * P0 * sizeof(float), h->stream));
+            hipStream_t st[2] = {h->stream, h->stream};
+            float* zs[2] = {w0.srow, w0.srow + (size_t)hb[0] * P0 * SROW};      // one zero buffer per half
+            float* zo[2] = {d_out + (size_t)b0 * P0, d_out + ((size_t)b0 + hb[0]) * P0};
+            if (nh == 2) {
+                if ((rc0 = ensure_second_stream(h))) return finish0(rc0);
+                st[1] = h->stream2;
+                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+            }
             for (int k = 0; k < h->n_blocks; ++k)
                 for (int i = 0; i < nh; ++i) {
+                    h->cur = st[i];
                     const size_t ns = (size_t)hb[i] * P0 * SROW;
-                    HIPCHK(h, hipMemsetAsync(w0.srow, 0, ns * sizeof(float), h->stream));
-                    if ((rc0 = allreduce(h, w0.srow, ns))) return rc0;
+                    if (hipMemsetAsync(zs[i], 0, ns * sizeof(float), st[i]) != hipSuccess) return finish0(fail(h, PF_EHIP, "hipMemsetAsync failed"));
+                    if ((rc0 = allreduce(h, zs[i], ns))) return finish0(rc0);
                 }
-            size_t o = (size_t)b0 * P0;
             for (int i = 0; i < nh; ++i) {
-                if ((rc0 = allreduce(h, d_out + o, (size_t)hb[i] * P0))) return rc0;
-                o += (size_t)hb[i] * P0;
+                h->cur = st[i];
+                if (hipMemsetAsync(zo[i], 0, (size_t)hb[i] * P0 * sizeof(float), st[i]) != hipSuccess) return finish0(fail(h, PF_EHIP, "hipMemsetAsync failed"));
+                if ((rc0 = allreduce(h, zo[i], (size_t)hb[i] * P0))) return finish0(rc0);
+            }
+            if (nh == 2) {
+                HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
         }
-        return PF_OK;
+        return finish0(PF_OK);
     }
     int rc = check_dims(h, B, N, Lloc, L_total);
     if (rc) return rc;
@@ -997,6 +997,7 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
     // chunk size is derived from the largest shard, not from this rank's own
     const int Lmax = h->world > 1 ? (L_total + h->world - 1) / h->world : Lloc;
     const int cb = chunk_batch(h, B, P, std::max(Lloc, Lmax));
+    if ((rc = trim_workspaces(h, chunk_bytes(h, cb, P, std::max(Lloc, Lmax))))) return rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nbch = std::min(cb, B - b0);
         rc = forward_chunk(h, d_idx + (size_t)b0 * N * Lloc, nbch, N, Lloc, L_total, d_out + (size_t)b0 * P);
@@ -1071,6 +1072,22 @@ static int open_device(int device, pf_handle** out) {
         }
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
         h->cur = h->stream;
+        // Kernels that need more than the default 64 KB of dynamic LDS: the attribute is set here, once per
+        // handle and before any launch, so that no launch path carries mutable state shared between handles
+        // (the CLI drives two engines per GPU from two host threads).
+        const struct { const void* fn; int bytes; } big_lds[] = {
+            {reinterpret_cast<const void*>(&k_main<MODE_FIRST>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_MID>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_MID0>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_LAST>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_embed), EMBED_LDS_BYTES},
+        };
+        for (const auto& k : big_lds)
+            if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess) {
+                rc = fail(nullptr, PF_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                break;
+            }
+        if (rc) break;
     } while (0);
     if (rc) { pf_destroy(h); return rc; }
     *out = h;
@@ -1110,7 +1127,8 @@ int pf_destroy(pf_handle_t* h) {
     if (!h) return PF_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->stream2) hipStreamSynchronize(h->stream2);
+    for (void*& c : h->comm) if (c && g_rccl.CommDestroy) { g_rccl.CommDestroy(c); c = nullptr; }
     for (auto& s : h->pending) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : h->free_events) hipEventDestroy(e);
     for (void* p : h->owned) hipFree(p);
@@ -1137,10 +1155,8 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "profile") { drain_profile(h); h->profile = value != 0; h->profile_main_only = value == 2; }
     else if (k == "debug_keep") h->debug_keep = value != 0;
     else if (k == "embed_mfma") h->embed_mfma = value != 0;
-    else if (k == "colstats_mfma") h->colstats_mfma = value != 0;
     else if (k == "colstats_fine") h->colstats_fine = value < 0 ? -1 : (value != 0);
     else if (k == "materialize_x0") h->materialize_x0 = value != 0;
-    else if (k == "main2") h->main2 = value != 0;
     else if (k == "overlap") h->overlap = value != 0;
     else if (k == "two_streams") h->two_streams = value != 0;
     else if (k == "reserve_cus") h->reserve_cus = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128));
@@ -1192,31 +1208,42 @@ int pf_comm_info(char* path_out, size_t path_cap, int32_t* version) {
     return PF_OK;
 }
 
+// PF_UNIQUE_ID_BYTES = two ncclUniqueIds back to back: one per communicator (one communicator per stream).
 int pf_comm_unique_id(void* id_out) {
     std::string err;
     if (!id_out) return PF_EINVAL;
     if (!load_rccl(err)) return fail(nullptr, PF_ERCCL, "%s", err.c_str());
-    int rc = g_rccl.GetUniqueId(id_out);
-    if (rc != 0) return fail(nullptr, PF_ERCCL, "ncclGetUniqueId failed (%d)", rc);
+    static_assert(PF_UNIQUE_ID_BYTES == 2 * sizeof(PfNcclId), "two ncclUniqueIds");
+    for (int i = 0; i < 2; ++i) {
+        int rc = g_rccl.GetUniqueId(static_cast<char*>(id_out) + i * sizeof(PfNcclId));
+        if (rc != 0) return fail(nullptr, PF_ERCCL, "ncclGetUniqueId failed (%d)", rc);
+    }
     return PF_OK;
 }
 
 int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t world_size) {
     if (!h || world_size < 1 || rank < 0 || rank >= world_size) return PF_EINVAL;
-    if (h->comm) return fail(h, PF_ESTATE, "communicator already initialised");
-    // rank / world are only recorded once the communicator exists: after a failed init the handle is
+    if (h->comm[0]) return fail(h, PF_ESTATE, "communicator already initialised");
+    // rank / world are only recorded once both communicators exist: after a failed init the handle is
     // still a working single-rank engine
     if (world_size == 1 && !h->force_rccl) { h->rank = 0; h->world = 1; return PF_OK; }
     if (!unique_id) return fail(h, PF_EINVAL, "null unique id");
     std::string err;
     if (!load_rccl(err)) return fail(h, PF_ERCCL, "%s", err.c_str());
     HIPCHK(h, hipSetDevice(h->device));
-    PfNcclId id;
-    std::memcpy(id.internal, unique_id, PF_UNIQUE_ID_BYTES);
-    int rc = g_rccl.CommInitRank(&h->comm, world_size, id, rank);
-    if (rc != 0) {
-        h->comm = nullptr;
-        return fail(h, PF_ERCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    int rc0 = ensure_second_stream(h);
+    if (rc0) return rc0;
+    // every rank creates communicator 0, then communicator 1, in this order (ncclCommInitRank is collective)
+    for (int i = 0; i < 2; ++i) {
+        PfNcclId id;
+        std::memcpy(id.internal, static_cast<const char*>(unique_id) + i * sizeof(PfNcclId), sizeof(PfNcclId));
+        int rc = g_rccl.CommInitRank(&h->comm[i], world_size, id, rank);
+        if (rc != 0) {
+            h->comm[i] = nullptr;
+            if (i == 1) { g_rccl.CommDestroy(h->comm[0]); h->comm[0] = nullptr; }
+            return fail(h, PF_ERCCL, "ncclCommInitRank (communicator %d) failed: %s", i,
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        }
     }
     h->rank = rank;
     h->world = world_size;
@@ -1225,7 +1252,11 @@ int pf_comm_init(pf_handle_t* h, const void* unique_id, int32_t rank, int32_t wo
 
 int pf_comm_destroy(pf_handle_t* h) {
     if (!h) return PF_EINVAL;
-    if (h->comm) { hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    if (h->comm[0] || h->comm[1]) {
+        hipStreamSynchronize(h->stream);
+        if (h->stream2) hipStreamSynchronize(h->stream2);
+        for (void*& c : h->comm) if (c) { g_rccl.CommDestroy(c); c = nullptr; }
+    }
     h->world = 1; h->rank = 0;
     return PF_OK;
 }
@@ -1271,12 +1302,18 @@ int pf_profile_reset(pf_handle_t* h) {
     if (!h) return PF_EINVAL;
     drain_profile(h);
     for (int i = 0; i < K_COUNT; ++i) { h->prof_n[i] = 0; h->prof_ms[i] = 0; }
+    h->coll_calls = 0;
     return PF_OK;
 }
 
 int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double* total_ms) {
     if (!h || !kernel) return PF_EINVAL;
     drain_profile(h);
+    if (std::strcmp(kernel, "collectives") == 0) {      // always counted, no event bracketing needed
+        if (launches) *launches = h->coll_calls;
+        if (total_ms) *total_ms = 0.0;
+        return PF_OK;
+    }
     for (int i = 0; i < K_COUNT; ++i)
         if (std::strcmp(kernel, KNAMES[i]) == 0) {
             if (launches) *launches = h->prof_n[i];

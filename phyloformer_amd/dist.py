@@ -11,7 +11,7 @@ Two ways to use several GPUs:
   collectives per forward, issued with ``ncclAllReduce`` on the engine's stream.
 * **alignment sharding** (independent alignments per rank): no collective.
 
-The host-side rendezvous (the 128-byte RCCL unique id, agreement flags, the
+The host-side rendezvous (the RCCL unique ids - 256 bytes, one id per communicator / stream -, agreement flags, the
 barriers of the benchmark) goes through :class:`phyloformer_amd.rendezvous.TcpGroup`
 (standard library only), so a rank never maps torch's bundled HIP runtime next to
 the one ``libphyloformer_amd.so`` is linked against.  A ``torch.distributed`` group
@@ -69,7 +69,8 @@ def broadcast_bytes(payload: Optional[bytes], nbytes: int, src: int = 0, group=N
     return bytes(buf.cpu().numpy().tobytes())
 
 
-_NO_ID = bytes(128)      # sentinel: rank 0 could not produce a unique id
+UNIQUE_ID_BYTES = 256    # include/phyloformer_amd.h: PF_UNIQUE_ID_BYTES (two ncclUniqueIds)
+_NO_ID = bytes(UNIQUE_ID_BYTES)      # sentinel: rank 0 could not produce a unique id
 
 
 def init_engine_comm(engine, group=None) -> Tuple[int, int]:
@@ -106,7 +107,7 @@ def init_engine_comm(engine, group=None) -> Tuple[int, int]:
             uid = engine.unique_id()
         except Exception as exc:  # noqa: BLE001 - reported to every rank below
             uid, why = _NO_ID, f"{type(exc).__name__}: {exc}"
-    uid = broadcast_bytes(uid, 128, src=0, group=group)
+    uid = broadcast_bytes(uid, UNIQUE_ID_BYTES, src=0, group=group)
     if uid == _NO_ID:
         raise RuntimeError("rank 0 could not create an RCCL unique id" + (f" ({why})" if why else ""))
     engine.comm_init(uid, rank, world)

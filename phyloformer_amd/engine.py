@@ -17,7 +17,8 @@ from .weights import ModelWeights
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libphyloformer_amd.so")
-UNIQUE_ID_BYTES = 128
+ABI_VERSION = 2            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
+UNIQUE_ID_BYTES = 256      # PF_UNIQUE_ID_BYTES: two ncclUniqueIds, one per communicator / stream
 
 PF_OK, PF_EINVAL, PF_EHIP, PF_ERCCL, PF_ENOMEM, PF_ESTATE = 0, -1, -2, -3, -4, -5
 
@@ -95,6 +96,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.pf_abi_version() != ABI_VERSION:
+        raise EngineError(PF_ESTATE, f"{p} has ABI version {lib.pf_abi_version()}, this binding expects "
+                          f"{ABI_VERSION}; rebuild with `python -m phyloformer_amd.build --force`")
     if path is None:
         _lib = lib
     return lib
@@ -248,6 +252,10 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.pf_comm_destroy(self._h))
         self.rank, self.world = 0, 1
+
+    def collective_count(self) -> int:
+        """All-reduces issued by this handle since the last ``profile_reset`` (always counted)."""
+        return self.profile_get("collectives")[0]
 
     def comm_info(self) -> dict:
         """Path and version of the librccl the native library resolved (loads it if necessary)."""

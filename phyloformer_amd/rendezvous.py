@@ -1,6 +1,6 @@
 """Torch-free rendezvous of the ranks of ONE node (the bench contract: one process per GPU).
 
-The only things the ranks of a site-sharded run exchange on the host are the 128-byte RCCL unique id, a few
+The only things the ranks of a site-sharded run exchange on the host are the 256-byte RCCL unique-id blob, a few
 agreement flags and the barriers / max-reduction of the benchmark.  Importing ``torch.distributed`` for that
 maps torch's bundled HIP runtime and librccl into a process whose hot path lives in
 ``libphyloformer_amd.so`` (linked against the system ROCm): two HIP runtimes in one address space.  This module

@@ -11,59 +11,10 @@ import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-class FakeEngine:
-    """Engine interface used by bench.run; records what it is asked to do."""
-
-    def __init__(self, rank, log, fail_comm_on=None):
-        self.rank, self.log, self.fail_comm_on = rank, log, fail_comm_on
-        self.bufs, self.comm = {}, False
-        self.calls = 0
-
-    def set_option(self, k, v): self.log.append(("opt", k, v))
-    def unique_id(self): return bytes(range(1, 129))
-
-    def comm_init(self, uid, rank, world):
-        if self.fail_comm_on == rank:
-            raise RuntimeError("ncclCommInitRank failed: unhandled system error")
-        assert uid == bytes(range(1, 129))
-        self.comm = True
-        self.log.append(("comm_init", rank, world))
-
-    def comm_info(self): return {"library": "/opt/rocm/lib/librccl.so.1", "version": 22707}
-    def comm_destroy(self): self.comm = False; self.log.append(("comm_destroy",))
-    def malloc(self, n): self.bufs[len(self.bufs) + 1] = n; return len(self.bufs)
-    def free(self, p): self.bufs.pop(p)
-    def h2d(self, d, a): self.log.append(("h2d", a.shape))
-    def d2h(self, out, d): out[...] = 0.25
-    def synchronize(self): pass
-    def profile_reset(self): pass
-    def profile_get(self, k): return (6 * self.calls, 4.0 * 6 * self.calls)
-    def device_info(self): return {"name": "fake gfx950", "cu_count": 256, "hbm_bytes": 1 << 38}
-    def close(self): self.log.append(("close",))
-
-    def forward_sharded_device(self, d_idx, B, N, lo, hi, L, d_out):
-        assert self.comm, "site-sharded step without a communicator"
-        self.calls += 1
-        self.log.append(("sharded", B, N, lo, hi, L))
-
-    def forward_device(self, d_idx, B, N, L, d_out):
-        assert not self.comm, "plain forward on a handle that still carries a communicator"
-        self.calls += 1
-        self.log.append(("plain", B, N, L))
-
-    def forward_sharded(self, idx, lo, hi, L):
-        assert self.comm
-        return np.full((idx.shape[0], idx.shape[1] * (idx.shape[1] - 1) // 2), 0.25, np.float32)
-
-    def forward(self, idx):
-        assert not self.comm
-        return np.full((idx.shape[0], idx.shape[1] * (idx.shape[1] - 1) // 2), 0.25, np.float32)
-
-
-class _W:
-    n_blocks = 6
+from helpers.fake_engine import FakeEngine, FakeWeights as _W  # noqa: E402
 
 
 def _worker(rank, world, key, tmp, fail_comm_on, q):
@@ -118,3 +69,66 @@ def test_bench_rank_logic_world2(fail_comm_on, tmp_path):
             assert len([e for e in log if e == ("plain", 2, 6, 45)]) == 8
         assert line["config"]["parallelism"] == "alignments-sharded x2" and line["config"]["global_batch"] == 4
         assert "RCCL init failed" in line["config"]["note"]
+
+
+def _run_bench(argv, env_extra, timeout=120):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), REPO, env.get("PYTHONPATH", "")])
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("fail_comm_on", ["", "1"])
+def test_bench_self_launch_world2(fail_comm_on, tmp_path):
+    """`python3 bench.py --gpus 2` with no launcher environment - the form the driver uses - starts its own two
+    ranks (fresh children, rendezvous over 127.0.0.1), relays rank 0's one JSON line and exits 0.  Fake engine:
+    this is the launch / rank logic, not the GPU."""
+    res = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--n-seqs", "6", "--n-sites", "45",
+                      "--no-power", "--launch-timeout", "60"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_for_bench", "PF_FAKE_LOG_DIR": str(tmp_path),
+                      "PF_FAKE_FAIL_COMM_ON": fail_comm_on, "TMPDIR": str(tmp_path)})
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["global_batch"] == 4
+    assert line["metric"].startswith("alignments/sec, 6-leaf/45-site") and line["config"]["workload"].startswith("not a BASELINE shape")
+    logs = [json.load(open(tmp_path / f"rank{r}.log")) for r in range(2)]
+    if fail_comm_on == "":
+        assert line["config"]["parallelism"] == "sites-sharded x2" and line["config"]["n_ranks_in_comm"] == 2
+        assert line["config"]["collectives_per_step"] == 14 and line["config"]["communicators"] == 2
+        assert line["config"]["reserve_cus"] == 8 and line["config"]["rccl"]["version"] == 22707
+        for rank, (lo, hi) in enumerate([(0, 23), (23, 45)]):
+            assert ["sharded", 4, 6, lo, hi, 45] in logs[rank] and ["comm_init", rank, 2] in logs[rank]
+    else:
+        assert line["config"]["parallelism"] == "alignments-sharded x2" and "RCCL init failed" in line["config"]["note"]
+        assert line["config"]["n_ranks_in_comm"] == 0 and line["config"]["collectives_per_step"] == 0
+        assert "falling back" in res.stderr
+
+
+def test_bench_self_launch_reports_a_dead_rank(tmp_path):
+    """A rank that dies takes the launch down with a non-zero exit code instead of leaving the others waiting."""
+    res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1", "--n-seqs", "4", "--n-sites", "33",
+                      "--no-power", "--launch-timeout", "60"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_dying_on_rank1", "TMPDIR": str(tmp_path)})
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert "rank 1 exited with code" in res.stderr
+
+
+def test_bench_self_launch_watchdog(tmp_path):
+    res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1", "--n-seqs", "4", "--n-sites", "33",
+                      "--no-power", "--launch-timeout", "3"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_hanging", "TMPDIR": str(tmp_path)})
+    assert res.returncode == 124 and "watchdog" in res.stderr
+
+
+def test_workload_label_follows_the_shape():
+    sys.path.insert(0, REPO)
+    import bench
+    m, w = bench.workload_label(60, 2000, "models/pf.ckpt")
+    assert "60-leaf/2000-site" in m and w.startswith("configs[3]")
+    assert bench.workload_label(60, 500, "pf.ckpt")[1].startswith("configs[2]")
+    assert bench.workload_label(200, 500, "pf_indel.ckpt")[1].startswith("configs[4]")
+    assert bench.workload_label(20, 200, "pf.ckpt")[1].startswith("configs[1]")

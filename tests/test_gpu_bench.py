@@ -1,0 +1,81 @@
+"""-m gpu: bench.py as the driver invokes it, on the 1-GPU box - the self-launched N > 1 path down to the
+agreed fallback, the site-sharded schedule with real (single-rank) RCCL communicators, and the library's
+promise that distinct handles are independent (two engines, two host threads, first forwards concurrently)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(argv, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus2_self_launch_on_one_gpu_falls_back_together():
+    """`python3 bench.py --gpus 2`, no launcher: the parent starts two ranks, both on device 0 here
+    (PF_BENCH_DEVICE=0).  RCCL refuses two ranks on one device; the ranks agree on that, destroy their
+    communicators and shard whole alignments instead - one JSON line, exit code 0."""
+    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--n-seqs", "20", "--n-sites", "200",
+                  "--no-cpu-baseline", "--no-power", "--launch-timeout", "240"], {"PF_BENCH_DEVICE": "0"})
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["workload"].startswith("configs[1]")
+    if line["config"]["parallelism"].startswith("alignments"):
+        assert "RCCL init failed" in line["config"]["note"] and line["config"]["collectives_per_step"] == 0
+    else:       # a box where RCCL accepts two ranks on one device: then the real thing ran
+        assert line["config"]["n_ranks_in_comm"] == 2 and line["config"]["collectives_per_step"] == 14
+    print("bench --gpus 2 on one GPU:", line["config"])
+
+
+def test_bench_force_dist_runs_fourteen_collectives():
+    """The N > 1 code path of bench.py (rendezvous, two RCCL communicators, two streams) with one rank."""
+    res = _bench(["--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-power", "--no-configs",
+                  "--batch", "4", "--n-seqs", "20", "--n-sites", "200"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert cfg["collectives_per_step"] == 14 and cfg["communicators"] == 2 and cfg["n_ranks_in_comm"] == 1
+    assert cfg["reserve_cus"] == 8 and cfg["rccl"]["version"] > 20000 and cfg["rccl"]["library"].endswith(".so.1")
+    assert line["roofline"]["launches"] == 12 and line["value"] > 0
+
+
+def test_two_engines_first_forward_from_two_threads(weights, golden):
+    """No process-global mutable state on the launch path: two handles created and driven through their FIRST
+    forward by two host threads at once give the bits of a lone engine."""
+    from phyloformer_amd.engine import Engine
+    g = golden("configs.npz")
+    a = g["c2_idx"]
+    with Engine(weights("pf"), 0) as e:
+        ref = e.forward(a)
+    start = threading.Barrier(2)
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            with Engine(weights("pf"), 0) as e:
+                start.wait(timeout=60)
+                out[i] = e.forward(a)              # first launch of every kernel on this handle
+                for _ in range(3):
+                    assert np.array_equal(e.forward(a), out[i])
+        except Exception as exc:  # noqa: BLE001
+            errs.append(repr(exc))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)

@@ -46,9 +46,9 @@ def test_config4_60x2000_eight_shards(engines, repo):
 
 
 def test_rccl_single_rank_communicator(weights, golden):
-    """dlopen(librccl), ncclGetUniqueId/CommInitRank/AllReduce on the engine's streams with one rank:
-    the collectives of a sharded forward (7 per half-batch, two halves for this batch of two) must leave the
-    result unchanged."""
+    """dlopen(librccl), ncclGetUniqueId/CommInitRank/AllReduce on the engine's two streams, each with its OWN
+    single-rank communicator (pf_comm_init creates two from the 256-byte id blob): the collectives of a sharded
+    forward (7 per half-batch, two halves for this batch of two) must leave the result unchanged."""
     from phyloformer_amd.engine import Engine
     g = golden("configs.npz")
     a = g["c2_idx"][:2]
@@ -60,6 +60,7 @@ def test_rccl_single_rank_communicator(weights, golden):
         e.profile_reset()
         got = e.forward_sharded(a, 0, 200, 200)
         n, _ms = e.profile_get("allreduce")
+        assert e.collective_count() == n          # the always-on counter agrees with the event-bracketed one
         info = e.comm_info()
         # the plain entry points never communicate, communicator or not (alignment-level data parallelism
         # on a handle that also serves site-sharded calls)
@@ -111,3 +112,36 @@ def test_overlapped_half_batches_equal_serial_schedule(weights, golden):
     assert ncoll == {0: 7, 1: 14}
     assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
     assert np.array_equal(single, ref[:1])
+
+
+def test_debug_taps_cover_the_whole_batch_when_collectives_run(weights, golden):
+    """with debug_keep a site-sharded forward must not be cut in two halves (each tap name holds
+    one tensor): 7 collectives, taps of the full batch, same distances."""
+    from phyloformer_amd.engine import Engine
+    a = golden("configs.npz")["c2_idx"][:2]
+    with Engine(weights("pf"), 0) as e:
+        ref = e.forward(a)
+        e.set_option("force_rccl", 1)
+        e.comm_init(e.unique_id(), 0, 1)
+        e.set_option("debug_keep", 1)
+        e.profile_reset()
+        got = e.forward_sharded(a, 0, 200, 200)
+        assert e.collective_count() == 7
+        assert e.debug_read("srow0").size == 2 * 190 * 72 and e.debug_read("x6").size == 2 * 190 * 200 * 64
+        e.set_option("debug_keep", 0)
+        e.comm_destroy()
+    assert np.array_equal(got, ref)
+
+
+def test_chunk_budget_counts_both_workspaces(weights, golden):
+    """the per-chunk budget (ws_limit_mb) bounds ws + ws2 together and uses the real column-statistics
+    plan; a batch chunked under a tight budget returns the bits of the unchunked run, on one and on two streams."""
+    from phyloformer_amd.engine import Engine
+    a = np.concatenate([golden("configs.npz")["c2_idx"]] * 4)[:11]          # 11 alignments of 20 x 200
+    with Engine(weights("pf"), 0) as e:
+        whole = e.forward(a)
+        for two in (1, 0, 1):
+            e.set_option("two_streams", two)
+            e.set_option("ws_limit_mb", 48)
+            assert np.array_equal(e.forward(a), whole)
+            e.set_option("ws_limit_mb", 24576)

@@ -113,7 +113,9 @@ def test_abi_symbols_exported(repo):
     assert declared and declared == set(engine.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pf_abi_version() == 1
+    abi = int(re.search(r"#define PF_ABI_VERSION (\d+)", header).group(1))
+    assert lib.pf_abi_version() == abi == engine.ABI_VERSION
+    assert int(re.search(r"#define PF_UNIQUE_ID_BYTES (\d+)", header).group(1)) == engine.UNIQUE_ID_BYTES
     assert lib.pf_blob_len(6, 4, 64) == 308449
 
 

@@ -24,7 +24,7 @@ class _FakeEngine:
     def unique_id(self):
         if self.fail_uid:
             raise OSError("librccl.so.1: cannot open shared object file")
-        return bytes((7 * i + 1) % 256 for i in range(128))
+        return bytes((7 * i + 1) % 256 for i in range(256))
 
     def comm_init(self, uid, rank, world):
         self.inited = (uid, rank, world)
@@ -77,7 +77,7 @@ def test_tcp_group_collectives_and_comm_bootstrap(world, fail_uid, tmp_path):
         else:
             uid, r, w = comm[1]
             assert comm[0] == "ok" and (r, w) == (rank, world)
-            assert uid == bytes((7 * i + 1) % 256 for i in range(128))
+            assert uid == bytes((7 * i + 1) % 256 for i in range(256))
     assert not [f for f in os.listdir(tmp_path) if f.startswith(key)], "rendezvous file left behind"
 
 
