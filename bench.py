@@ -526,14 +526,22 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
+    # Native libraries write to file descriptor 1 as they please (RCCL prints a version banner there when a
+    # communicator fails): the contract is ONE JSON line on stdout, so descriptor 1 is pointed at stderr for the
+    # life of the rank and the line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     from phyloformer_amd.rendezvous import TcpGroup
     w, make_engine, make_engine_for = engine_factories(args.ckpt)
     group = TcpGroup(rank, world) if (world > 1 or args.force_dist) else None
     try:
-        run(args, rank, world, local_rank, group, make_engine, w, make_engine_for=make_engine_for)
+        run(args, rank, world, local_rank, group, make_engine, w, out=line_out, make_engine_for=make_engine_for)
     finally:
         if group is not None:
             group.close()
+        line_out.flush()
     return 0
 
 

@@ -39,8 +39,14 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
+    # -amdgpu-sched-strategy=iterative-ilp: with the default (max-occupancy) strategy hipcc sinks the software-
+    # pipelined LDS fragment reads of k_main's hidden loop down to their first use (read - wait - MFMA, one at a
+    # time, a single fragment buffer) whenever code outside the loop changes - +7 % on the loop between two builds
+    # with identical loop source (round 3); the iterative ILP strategy keeps the read pairs
+    # ahead of the MFMAs and is 1.3 % faster on the forward (k_colstats gains too).
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-fno-slp-vectorize", "-Wno-unused-value", *SOURCES, "-o", LIB + ".tmp", "-ldl"]
+           "-fno-slp-vectorize", "-Wno-unused-value", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+           *SOURCES, "-o", LIB + ".tmp", "-ldl"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)

@@ -127,10 +127,47 @@ __device__ __forceinline__ void treduce_step(float* v, int t) {
         v[i] = keep + (DPP_CTRL ? dpp_f<DPP_CTRL>(send) : swz_xor<16>(send));
     }
 }
+// The same step without the two selects per value pair (they were half of the reduction's VALU instructions).
+// Lanes whose bit log2(M) is clear want v[i] + partner's v[i], the others v[i + M] + partner's v[i + M]:
+//   M = 16: v_permlane16_swap exchanges the odd 16-lane rows of v[i] with the even rows of v[i + M]; the sum of
+//           the two registers is then exactly that (one swap + one add instead of two selects, a swizzle and an add);
+//   M = 8, 4: two DPP adds, each enabled (bank_mask) only for the lanes it is meant for - banks are 4-lane groups,
+//           so bit 3 / bit 2 of the lane selects {0, 1} vs {2, 3} / {0, 2} vs {1, 3}; disabled lanes keep v[i].
+// Operands and their pairing are those of treduce_step (own value + partner's value: the same fp32 sums).
+__device__ __forceinline__ void treduce_step16_swap(float* v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+#define PF_DPP_PAIR(D, S, CTRL, M0, M1) \
+    "v_add_f32_dpp " D ", " D ", " D " " CTRL " row_mask:0xf bank_mask:" M0 "\n\tv_add_f32_dpp " D ", " S ", " S " " CTRL " row_mask:0xf bank_mask:" M1 "\n\t"
+// One asm block per step.  Hazard (not interlocked on gfx9): a DPP read of a VGPR needs two wait states after the
+// VALU write of that VGPR, and hipcc pads nothing in front of or inside an asm statement - hence the s_nop 1 at
+// both ends (inside the block no DPP source is written by an earlier instruction of the block).
+__device__ __forceinline__ void treduce_step8_masked(float* v) {
+    asm("s_nop 1\n\t"
+        PF_DPP_PAIR("%0", "%8", "row_mirror", "0x3", "0xc") PF_DPP_PAIR("%1", "%9", "row_mirror", "0x3", "0xc")
+        PF_DPP_PAIR("%2", "%10", "row_mirror", "0x3", "0xc") PF_DPP_PAIR("%3", "%11", "row_mirror", "0x3", "0xc")
+        PF_DPP_PAIR("%4", "%12", "row_mirror", "0x3", "0xc") PF_DPP_PAIR("%5", "%13", "row_mirror", "0x3", "0xc")
+        PF_DPP_PAIR("%6", "%14", "row_mirror", "0x3", "0xc") PF_DPP_PAIR("%7", "%15", "row_mirror", "0x3", "0xc")
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+        : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+}
+__device__ __forceinline__ void treduce_step4_masked(float* v) {
+    asm("s_nop 1\n\t"
+        PF_DPP_PAIR("%0", "%4", "row_half_mirror", "0x5", "0xa") PF_DPP_PAIR("%1", "%5", "row_half_mirror", "0x5", "0xa")
+        PF_DPP_PAIR("%2", "%6", "row_half_mirror", "0x5", "0xa") PF_DPP_PAIR("%3", "%7", "row_half_mirror", "0x5", "0xa")
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])
+        : "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
 __device__ __forceinline__ float treduce32(float (&v)[32], int t) {
-    treduce_step<16, 0>(v, t);
-    treduce_step<8, 0x140>(v, t);
-    treduce_step<4, 0x141>(v, t);
+    treduce_step16_swap(v);
+    treduce_step8_masked(v);
+    treduce_step4_masked(v);
     treduce_step<2, 0x1B>(v, t);
     treduce_step<1, 0xB1>(v, t);
     return v[0];
@@ -140,7 +177,7 @@ __device__ __forceinline__ float treduce32(float (&v)[32], int t) {
 // Three transposing steps inside each 8-lane group (DPP only), then two plain all-reduce steps across the
 // four groups: 9 shuffle-adds instead of 8 x 5.
 __device__ __forceinline__ float treduce8(float (&v)[8], int t) {
-    treduce_step<4, 0x141>(v, t);
+    treduce_step4_masked(v);
     treduce_step<2, 0x1B>(v, t);
     treduce_step<1, 0xB1>(v, t);
     float r = v[0];
@@ -363,6 +400,10 @@ struct MainArgs {
     const int16_t* pair_i;  // [P]                                    (MODE_FIRST)
     const int16_t* pair_j;  // [P]
     int B, N, P, Lloc;
+    int flat;               // tiling (tile_plan() on the host): 0 = every pair row has its own ceil(L / 32) tiles,
+                            // 1 = the P * L tokens of an alignment are cut into tiles of 32 consecutive tokens
+    int nt_aln;             // tiles per alignment
+    int slots_aln;          // per-tile partial slots per alignment (spart / outpart): nt_aln, + P when flat
     size_t trash_tok;       // token index of a 32-token scratch area behind x and qrow (masked lanes)
     int store_x_last;       // debug: MODE_LAST also writes x back
     unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
@@ -400,7 +441,62 @@ __device__ __forceinline__ bf16x8 zero_frag() {
     return z;
 }
 
-// Work item = one tile of 32 consecutive sites of one (alignment, pair) row.  The B * P * ntiles tiles
+// Two tilings of an alignment's P x L tokens into work items of 32 tokens share the kernel:
+//   row tiling  (flat = 0): every pair row is cut into ceil(L / 32) tiles of its own; the last tile of a row is
+//               ragged (L = 500: 20 of 32 lanes valid, 2.3 % of all MFMA columns wasted; L = 200: 10.7 %);
+//   flat tiling (flat = 1; the host picks it when L >= 32 and L % 32 != 0): the alignment's P * L tokens - they
+//               are contiguous in x, qrow and qcol - are cut into tiles of 32 CONSECUTIVE tokens, so a tile
+//               may cover the last sites of row r0 and the first of row r0 + 1 (L >= 32: never more than two
+//               rows); only the alignment's last tile is ragged.  What is per row - the row-mix fragments, the
+//               statistics partial, the head sum - is then done once per row PART of such a tile.
+// Partials: a tile part owns slot (kt + its row) in flat tiling, kt in row tiling; the parts of row p are the
+// consecutive slots part_range() names, summed in slot order by k_rowfin / k_rowsum / k_outsum.  The tiling is
+// per alignment, a function of (P, L) only: an alignment gets the same bits wherever it sits in a batch.
+struct TilePos { int b, kt, r0, l0; };   // alignment, tile inside it, row of its first token, site of that token
+__device__ __forceinline__ TilePos tile_pos(const MainArgs& a, int task, int ntiles) {
+    TilePos q;
+    q.b = task / a.nt_aln;
+    q.kt = task - q.b * a.nt_aln;
+    if (a.flat) { const int tok0 = q.kt * 32; q.r0 = tok0 / a.Lloc; q.l0 = tok0 - q.r0 * a.Lloc; }
+    else { q.r0 = q.kt / ntiles; q.l0 = (q.kt - q.r0 * ntiles) * 32; }
+    return q;
+}
+__device__ __forceinline__ TilePos tile_next(const MainArgs& a, TilePos q) {
+    if (++q.kt == a.nt_aln) { q.b++; q.kt = 0; q.r0 = 0; q.l0 = 0; return q; }
+    q.l0 += 32;
+    if (q.l0 >= a.Lloc) { q.l0 = a.flat ? q.l0 - a.Lloc : 0; q.r0++; }
+    return q;
+}
+// lane t of a tile: its row (inside the alignment), its site, whether it holds a token at all and whether that
+// token belongs to the tile's second row.  Lanes without a token are clamped onto a real one (finite values,
+// their statistics are masked and their stores go to the trash area).
+// Everything that can be is wave-uniform: tok0 (the tile's first token, counted over the batch: tokens of a tile
+// are consecutive in both tilings), nvalid (lanes holding a token; < 32 only in a row's / an alignment's last
+// tile) and wrap (flat tiling: lanes from `wrap` on belong to row r0 + 1; 32 = none).  Per lane that leaves
+// one min for the clamped token offset and a compare + select for the site.
+struct LanePos { size_t tok0; int toff, l, nvalid, wrap; bool valid, in_r1; };
+__device__ __forceinline__ LanePos lane_pos(const MainArgs& a, const TilePos& q, int t) {
+    LanePos o;
+    o.tok0 = ((size_t)q.b * a.P + q.r0) * a.Lloc + q.l0;
+    const int left = a.flat ? a.P * a.Lloc - q.kt * 32 : a.Lloc - q.l0;      // tokens from the tile's first one on
+    o.nvalid = min(32, left);
+    o.wrap = (a.flat && q.r0 + 1 < a.P) ? min(32, a.Lloc - q.l0) : 32;
+    o.valid = t < o.nvalid;
+    o.toff = min(t, o.nvalid - 1);
+    o.in_r1 = o.toff >= o.wrap;
+    o.l = q.l0 + o.toff - (o.in_r1 ? a.Lloc : 0);
+    return o;
+}
+// Slots [first, first + count) of the partial buffers that hold row p's (pr = b * P + p) parts.
+__device__ __forceinline__ void part_range(int flat, int pr, int nparts, int P, int L, int slots_aln, long* first, int* count) {
+    if (!flat) { *first = (long)pr * nparts; *count = nparts; return; }
+    const int b = pr / P, p = pr - b * P;
+    const int k0 = (int)(((long)p * L) >> 5), k1 = (int)((((long)p + 1) * L - 1) >> 5);
+    *first = (long)b * slots_aln + k0 + p;
+    *count = k1 - k0 + 1;
+}
+
+// Work item = one tile of 32 tokens (see above).  The tiles
 // are dealt to the waves in short runs of consecutive tiles, round-robin; waves never synchronise with
 // each other after the LDS image is loaded.  Row statistics leave the kernel as one
 // 72-float partial per TILE (summed in fixed order by k_rowfin / k_rowsum), never as per-wave running sums:
@@ -436,7 +532,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     const int t = lane & 31;
     const int h = lane >> 5;
     const int ntiles = (a.Lloc + 31) >> 5;
-    const long ntasks = (long)a.B * a.P * ntiles;
+    const int ntasks = a.B * a.nt_aln;           // < 2^31: the host cuts larger batches into chunks
     // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per
     // SIMD, item 4: the younger wave otherwise loses every VALU arbitration): -0.3 % launch time, A/B measured
     if (wave >= MAIN_WAVES / 2) __builtin_amdgcn_s_setprio(1);
@@ -458,28 +554,28 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         // every wave in a different alignment and cost 0.7 GiB of extra L2 misses per launch (FETCH_SIZE 2.67
         // -> 1.99 GiB, tools/fetch_ab.sh; the launch itself is 1 % slower this way, run lengths 2..16 alike)
         // - while a wave still streams `run` consecutive 8 KB tiles and the load stays balanced to one run.
-        const long nwaves = (long)gridDim.x * MAIN_WAVES;
+        const int nwaves = gridDim.x * MAIN_WAVES;
 #ifndef PF_RUN_MAX
 #define PF_RUN_MAX 8
 #endif
-        const long run = max(1L, min((long)PF_RUN_MAX, ntasks / (nwaves * 8)));
-        long run0 = (long)(blockIdx.x * MAIN_WAVES + wave) * run;      // first tile of this wave's current run
-        const long task0 = run0, task1 = ntasks;
-        int row = (int)(min(task0, ntasks - 1) / ntiles);            // b * P + p
-        int tile = (int)(min(task0, ntasks - 1) - (long)row * ntiles);
-        int frag_row = -1;                          // the row whose row-mix fragments are in mfr
+        const int run = max(1, min(PF_RUN_MAX, ntasks / (nwaves * 8)));
+        int run0 = (blockIdx.x * MAIN_WAVES + wave) * run;             // first tile of this wave's current run
+        const int task0 = run0, task1 = ntasks;
+        TilePos cur = tile_pos(a, min(task0, ntasks - 1), ntiles);
+        int frag_row = -1;                          // the row (b * P + p) whose row-mix fragments are in mfr
         bf16x8 mfr[4];
         // The next tile's residual rows and q' are requested when the FFN of the current tile starts
         // (the residual lives in the GEMM2 accumulators from then on, see below) and land during
         // its ~6 us of matrix work, so a tile never starts by waiting on HBM.
         f32x4 px[8], pctx[8], pqr, pqc;
         int pri = 0, prj = 0;                       // MODE_MID0: residues of the next tile's site in both sequences
-        auto prefetch = [&](int prow, int ptile) {
-            const int ll = min(ptile * 32 + t, a.Lloc - 1);
-            const size_t tk = (size_t)prow * a.Lloc + ll;
+        auto prefetch = [&](const TilePos& np) {
+            const LanePos nl = lane_pos(a, np, t);
+            const int ll = nl.l, pb = np.b;
+            const size_t tk = nl.tok0 + nl.toff;
             if (MODE == MODE_MID0) {
-                const int pb = prow / a.P, pp = prow - pb * a.P;
                 const uint8_t* ib = a.idx + (size_t)pb * a.N * a.Lloc + ll;
+                const int pp = np.r0 + (nl.in_r1 ? 1 : 0);
                 pri = ib[(size_t)a.pair_i[pp] * a.Lloc];
                 prj = ib[(size_t)a.pair_j[pp] * a.Lloc];
             } else {
@@ -490,43 +586,40 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             pqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
             pqc = *reinterpret_cast<const f32x4*>(a.qcol + tk * 4);
             if (MODE != MODE_FIRST) {
-                const int pb = prow / a.P;
                 const f32x4* cp = reinterpret_cast<const f32x4*>(a.ctx + ((size_t)pb * a.Lloc + ll) * 64 + 4 * h);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) pctx[g] = cp[2 * g];
             }
         };
-        if (MODE != MODE_FIRST && task0 < task1) prefetch(row, tile);
+        if (MODE != MODE_FIRST && task0 < task1) prefetch(cur);
 
-        for (long task = task0; task < task1;) {
-            const int b = row / a.P;
-            const int p = row - b * a.P;
-            const size_t row0 = (size_t)row * a.Lloc;  // first token of this pair row
+        for (int task = task0; task < task1;) {
+            const int b = cur.b;
+            const int row = b * a.P + cur.r0;          // the tile's (first) row, counted over the batch
             // the tile that follows: the next one of this run, or the first one of the wave's next run
-            long ntask = task + 1;
-            int ntile = (tile + 1 < ntiles) ? tile + 1 : 0;
-            int nrow = (tile + 1 < ntiles) ? row : row + 1;
+            int ntask = task + 1;
+            TilePos nxt = tile_next(a, cur);
             if (ntask == run0 + run) {
                 run0 += nwaves * run;
                 ntask = run0;
-                if (ntask < task1) {
-                    nrow = (int)(ntask / ntiles);
-                    ntile = (int)(ntask - (long)nrow * ntiles);
-                }
+                if (ntask < task1) nxt = tile_pos(a, ntask, ntiles);
             }
+            const LanePos lp = lane_pos(a, cur, t);
+            // flat tiling: does this tile end row r0 and start row r0 + 1 (wave-uniform)?
+            const bool straddle = lp.wrap < 32;
             int ai = 0, aj = 0;
-            if (MODE == MODE_FIRST) { ai = a.pair_i[p]; aj = a.pair_j[p]; }
-            if (MODE != MODE_FIRST && row != frag_row) {
-                // the pair's row-mix fragments are loaded once per row, not once per tile
-                const bf16x8* mf = a.mfrag + (size_t)row * 128 + t;
+            if (MODE == MODE_FIRST) { const int pp = cur.r0 + (lp.in_r1 ? 1 : 0); ai = a.pair_i[pp]; aj = a.pair_j[pp]; }
+            auto load_mfr = [&](int r) {
+                const bf16x8* mf = a.mfrag + (size_t)r * 128 + t;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) mfr[q] = mf[q * 32];
-                frag_row = row;
-            }
-            const int l = tile * 32 + t;
-            const bool valid = l < a.Lloc;
-            const int lc_ = valid ? l : a.Lloc - 1;  // clamped site for gathers
-            const size_t tok = row0 + lc_;
+                frag_row = r;
+            };
+            // the pair's row-mix fragments are loaded once per row, not once per tile
+            if (MODE != MODE_FIRST && row != frag_row) load_mfr(row);
+            const bool valid = lp.valid;
+            const int lc_ = lp.l;                      // (clamped) site for gathers
+            const size_t tok = lp.tok0 + lp.toff;
             float x[32];
 
             if (MODE == MODE_FIRST) {
@@ -571,17 +664,26 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     // ---- row attention apply (block k) incl. the out_proj biases: K = {q'[0..3], 1}
                     {
                         const f32x4 qr = pqr;
-                        float v[8];
+                        // a tile over two rows applies each row's mix to its own tokens: the other row's
+                        // tokens get an all-zero B column (q' and both bias slots)
+                        auto mix = [&](const bool mine) {
+                            float v[8];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = (h == 0) ? qr[i] : 0.f;
-                        v[4] = v[5] = (h == 0) ? 1.f : 0.f;   // K slot 4: row out_proj bias, slot 5: column's
-                        v[6] = v[7] = 0.f;
-                        bf16x8 qb_hi, qb_lo;
-                        split8(v, qb_hi, qb_lo);
-                        // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do, so
-                        // they hold their partner's fragment instead of a masked load
+                            for (int i = 0; i < 4; ++i) v[i] = mine ? qr[i] : 0.f;
+                            v[4] = v[5] = mine ? 1.f : 0.f;   // K slot 4: row out_proj bias, slot 5: column's
+                            v[6] = v[7] = 0.f;
+                            bf16x8 qb_hi, qb_lo;
+                            split8(v, qb_hi, qb_lo);
+                            // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do, so
+                            // they hold their partner's fragment instead of a masked load
 #pragma unroll
-                        for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo, To == 1);
+                            for (int To = 0; To < 2; ++To) mfma3(ya[To], mfr[To * 2], mfr[To * 2 + 1], qb_hi, qb_lo, To == 1);
+                        };
+                        mix(h == 0 && !lp.in_r1);
+                        if (straddle) {                 // the next tile starts in row r0 + 1: its fragments stay
+                            load_mfr(row + 1);
+                            mix(h == 0 && lp.in_r1);
+                        }
                     }
                     // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
                     {
@@ -626,7 +728,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     load_acc_bias(oa[1], lch + CONST_B2 + 32);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) oa[j >> 4][j & 15] += x[j];
-                    if (ntask < task1) prefetch(nrow, ntile);
+                    if (ntask < task1) prefetch(nxt);
                     PF_TICK(2);
 #pragma unroll 1
                     for (int T = 0; T < 8; ++T) {
@@ -689,7 +791,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         xo[2 * g] = u;
                     }
                 }
-                if (a.ablate & 32) { tile = ntile; row = nrow; task = ntask; continue; }   // perf experiment: copy-only
+                if (a.ablate & 32) { cur = nxt; task = ntask; continue; }   // perf experiment: copy-only
                 f32x16 va[3];
                 {
                     float xn[32];
@@ -728,27 +830,34 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     qn[i] = h ? ot[i] : qk[i];
                     kn[i] = h ? qk[i] : ot[i];
                 }
-                float* sp = a.spart + (size_t)task * SROW;      // this tile's partial statistics
                 {
-                    const float vm = valid ? 1.f : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) kn[i] *= vm;
                     // both half-waves hold the same q'; all lanes store (no branch, see above)
                     const size_t stok = valid ? tok : a.trash_tok + t;
                     f32x4 qs = {qn[0], qn[1], qn[2], qn[3]};
                     *reinterpret_cast<f32x4*>(a.qrow + stok * 4) = qs;
-                    // S_q | S_k of the tile: lane j (mod 8) ends up with the half-wave sum of value j
-                    float qk8[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { qk8[i] = vm * qn[i]; qk8[4 + i] = kn[i]; }
-                    const float sqk = treduce8(qk8, t);
-                    if (lane < 8) sp[64 + lane] = sqk;
                 }
-                {
-                    float kv[32];
+                // one partial per row part of the tile: slot kt (+ row in flat tiling)
+                const long slot0 = (long)b * a.slots_aln + cur.kt + (a.flat ? cur.r0 : 0);
+                for (int part = 0; part < (straddle ? 2 : 1); ++part) {
+                    float* sp = a.spart + (size_t)(slot0 + part) * SROW;
+                    const float vm = (valid && lp.in_r1 == (part == 1)) ? 1.f : 0.f;
+                    float km[4];
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) kv[j] = kn[j >> 3] * va[j >> 4][j & 15];   // kn is masked
-                    sp[kmap(t, h)] = treduce32(kv, t);      // lane (t, h) owns S_kv[kmap(t, h)]
+                    for (int i = 0; i < 4; ++i) km[i] = kn[i] * vm;
+                    {
+                        // S_q | S_k of the part: lane j (mod 8) ends up with the half-wave sum of value j
+                        float qk8[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { qk8[i] = vm * qn[i]; qk8[4 + i] = km[i]; }
+                        const float sqk = treduce8(qk8, t);
+                        if (lane < 8) sp[64 + lane] = sqk;
+                    }
+                    {
+                        float kv[32];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) kv[j] = km[j >> 3] * va[j >> 4][j & 15];
+                        sp[kmap(t, h)] = treduce32(kv, t);      // lane (t, h) owns S_kv[kmap(t, h)]
+                    }
                 }
             } else if (MODE == MODE_LAST) {
                 // ---- head: softplus(w.x + b) summed over sites (model.py:182-185)
@@ -760,8 +869,12 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int i = 0; i < 4; ++i) z = fmaf(w4[i], x[4 * g + i], z);
                 }
                 z = pair_sum(z) + lc[CONST_HB];
-                const float so = half32_sum(valid ? softplus20(z) : 0.f);
-                if (lane == 0) a.outpart[task] = so;
+                const float spz = softplus20(z);
+                const long slot0 = (long)b * a.slots_aln + cur.kt + (a.flat ? cur.r0 : 0);
+                for (int part = 0; part < (straddle ? 2 : 1); ++part) {
+                    const float so = half32_sum((valid && lp.in_r1 == (part == 1)) ? spz : 0.f);
+                    if (lane == 0) a.outpart[slot0 + part] = so;
+                }
                 if (a.store_x_last && valid) {
                     f32x4* xo = reinterpret_cast<f32x4*>(a.x + tok * 64 + 4 * h);
 #pragma unroll
@@ -772,8 +885,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 }
             }
             PF_TICK(4);
-            tile = ntile;
-            row = nrow;
+            cur = nxt;
             task = ntask;
         }
     }
@@ -902,6 +1014,7 @@ struct RowFinArgs {
     const float* bias_col;  // [64] column out_proj bias of the same block
     int npairs, nparts;
     float L_total;
+    int flat, P, Lloc, slots_aln;   // where a pair's partials are (part_range): nparts each, or k_main's flat tiling
 };
 
 __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
@@ -921,19 +1034,22 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     const float bvc = a.bv[c], biasc = a.bias[c], biascol = a.bias_col[c];
     if (ok) {
         // partial statistics are summed in index order: the association is a function of the shape only
-        const float* sp = a.srow + (size_t)pr * a.nparts * SROW;
+        long first;
+        int nparts;
+        part_range(a.flat, pr, a.nparts, a.P, a.Lloc, a.slots_aln, &first, &nparts);
+        const float* sp = a.srow + (size_t)first * SROW;
         // lanes 0..63 take S_kv[c], lanes 0..7 also S_q | S_k; four partials in flight per lane
         const int c2 = 64 + (c & 7);
         float acc = 0.f, acc2 = 0.f;
         int i = 0;
-        for (; i + 4 <= a.nparts; i += 4) {
+        for (; i + 4 <= nparts; i += 4) {
             const float* q0 = sp + i * SROW;
             const float v0 = q0[c], v1 = q0[SROW + c], v2 = q0[2 * SROW + c], v3 = q0[3 * SROW + c];
             const float w0 = q0[c2], w1 = q0[SROW + c2], w2 = q0[2 * SROW + c2], w3 = q0[3 * SROW + c2];
             acc = (((acc + v0) + v1) + v2) + v3;
             acc2 = (((acc2 + w0) + w1) + w2) + w3;
         }
-        for (; i < a.nparts; ++i) {
+        for (; i < nparts; ++i) {
             acc += sp[i * SROW + c];
             acc2 += sp[i * SROW + c2];
         }
@@ -979,21 +1095,28 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
 }
 
 // per-tile partial statistics -> one [72] row per pair (site-sharded runs all-reduce this; debug taps)
-__global__ void k_rowsum(const float* spart, float* srow, int npairs, int nparts) {
+__global__ void k_rowsum(const float* spart, float* srow, int npairs, int nparts_, int flat, int P, int Lloc, int slots_aln) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npairs * SROW) return;
     const int pr = i / SROW, c = i - pr * SROW;
-    const float* sp = spart + (size_t)pr * nparts * SROW + c;
+    long first;
+    int nparts;
+    part_range(flat, pr, nparts_, P, Lloc, slots_aln, &first, &nparts);
+    const float* sp = spart + (size_t)first * SROW + c;
     float acc = 0.f;
     for (int k = 0; k < nparts; ++k) acc += sp[(size_t)k * SROW];
     srow[i] = acc;
 }
 
 // per-tile softplus sums of the last block -> distances (site mean, model.py:185)
-__global__ void k_outsum(const float* outpart, float* out, int npairs, int nparts, float inv_L_total) {
+__global__ void k_outsum(const float* outpart, float* out, int npairs, int nparts_, float inv_L_total, int flat, int P,
+                         int Lloc, int slots_aln) {
     const int pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= npairs) return;
-    const float* sp = outpart + (size_t)pr * nparts;
+    long first;
+    int nparts;
+    part_range(flat, pr, nparts_, P, Lloc, slots_aln, &first, &nparts);
+    const float* sp = outpart + first;
     float acc = 0.f;
     for (int k = 0; k < nparts; ++k) acc += sp[k];
     out[pr] = acc * inv_L_total;

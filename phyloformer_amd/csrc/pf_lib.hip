@@ -514,6 +514,20 @@ int ensure_pairs(pf_handle* h, int N) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// How k_main cuts an alignment's P x Lloc tokens into 32-token tiles (pf_device.hip.h, tile_pos): a function of
+// the shape only.  Flat tiling - tiles of 32 consecutive tokens that may cover the end of one pair row and the
+// start of the next - whenever rows are at least one tile long and not a whole number of tiles; otherwise every
+// row has its own ceil(Lloc / 32) tiles.
+struct TilePlan { int flat, nt_aln, slots_aln; };
+TilePlan tile_plan(int P, int Lloc) {
+    TilePlan t;
+    const int ntiles = (Lloc + 31) / 32;
+    t.flat = (Lloc >= 32 && Lloc % 32 != 0 && getenv("PF_ROW_TILES") == nullptr) ? 1 : 0;
+    t.nt_aln = t.flat ? (int)(((long)P * Lloc + 31) / 32) : P * ntiles;
+    t.slots_aln = t.flat ? t.nt_aln + P : t.nt_aln;
+    return t;
+}
+
 struct Workspace {
     float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag, *spart, *outpart;
     int G;             // pair groups of k_colstats
@@ -567,9 +581,9 @@ size_t workspace_bytes(int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) 
     off[5] = o; o = align_up(o + (size_t)B * nparts * Lloc * CPART * 4, 256); // part
     off[6] = o; o = align_up(o + (size_t)B * Lloc * 64 * 4, 256);        // ctx
     off[7] = o; o = align_up(o + (size_t)B * P * MFRAG_PER_PAIR * 16, 256); // mfrag
-    const size_t ntiles = (size_t)(Lloc + 31) / 32;
-    off[8] = o; o = align_up(o + (size_t)B * P * ntiles * SROW * 4, 256);   // spart: per-tile row statistics
-    off[9] = o; o = align_up(o + (size_t)B * P * ntiles * 4, 256);          // outpart: per-tile head sums
+    const size_t slots = (size_t)tile_plan(P, Lloc).slots_aln;
+    off[8] = o; o = align_up(o + (size_t)B * slots * SROW * 4, 256);   // spart: row statistics per tile part
+    off[9] = o; o = align_up(o + (size_t)B * slots * 4, 256);          // outpart: head sums per tile part
     return o;
 }
 
@@ -653,7 +667,7 @@ int allreduce(pf_handle* h, float* buf, size_t count) {
 
 template <int MODE>
 int launch_main(pf_handle* h, const MainArgs& a, int kid) {
-    const long ntasks = (long)a.B * a.P * ((a.Lloc + 31) / 32);      // one work item per 32-site tile
+    const long ntasks = (long)a.B * a.nt_aln;                        // one work item per 32-token tile
     const int cus = std::max(1, h->prop.multiProcessorCount - (h->reducing ? h->reserve_cus : 0));
     const int grid = (int)std::max<long>(1, std::min<long>(cus, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
     ProfScope ps(h, kid);
@@ -676,6 +690,8 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
     m.mfrag = reinterpret_cast<const bf16x8*>(r.w.mfrag); m.ctx = r.w.ctx; m.spart = r.w.spart;
     m.outpart = r.w.outpart; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
     m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc;
+    const TilePlan tp = tile_plan(r.P, r.Lloc);
+    m.flat = tp.flat; m.nt_aln = tp.nt_aln; m.slots_aln = tp.slots_aln;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.trash_tok = (size_t)r.B * r.P * r.Lloc;
     m.ablate = h->ablate;
@@ -715,7 +731,8 @@ int phase_first(pf_handle* h, const ShardRun& r) {
 
 // Row statistics feeding a block: `nparts` partial sums of 72 floats per pair (k_main leaves one per tile,
 // k_embed and the reduced / all-reduced form one).
-struct RowStats { const float* p; int nparts; };
+struct RowStats { const float* p; int nparts; int flat; };   // flat: k_main's per-part slots (part_range) instead of
+                                                            // nparts consecutive partials per pair
 
 int tiles_of(int Lloc) { return (Lloc + 31) / 32; }
 
@@ -724,9 +741,10 @@ int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
     if (rs->p == r.w.srow) return PF_OK;             // already one row per pair, in place
     const int n = r.B * r.P * SROW;
     ProfScope ps(h, K_ROWFIN);
-    hipLaunchKernelGGL(k_rowsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, rs->p, r.w.srow, r.B * r.P, rs->nparts);
+    hipLaunchKernelGGL(k_rowsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, rs->p, r.w.srow, r.B * r.P, rs->nparts,
+                       rs->flat, r.P, r.Lloc, tile_plan(r.P, r.Lloc).slots_aln);
     HIPCHK(h, hipGetLastError());
-    *rs = RowStats{r.w.srow, 1};
+    *rs = RowStats{r.w.srow, 1, 0};
     return PF_OK;
 }
 
@@ -734,16 +752,20 @@ int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
 int launch_outsum(pf_handle* h, const ShardRun& r) {
     const int n = r.B * r.P;
     ProfScope ps(h, K_ROWFIN);
+    const TilePlan tp = tile_plan(r.P, r.Lloc);
     hipLaunchKernelGGL(k_outsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, r.w.outpart, r.d_out, n,
-                       tiles_of(r.Lloc), 1.0f / (float)r.L_total);
+                       tiles_of(r.Lloc), 1.0f / (float)r.L_total, tp.flat, r.P, r.Lloc, tp.slots_aln);
     HIPCHK(h, hipGetLastError());
     return PF_OK;
 }
 
+// the per-part statistics a k_main launch leaves in spart
+RowStats main_stats(const ShardRun& r) { return RowStats{r.w.spart, tiles_of(r.Lloc), tile_plan(r.P, r.Lloc).flat}; }
+
 // where block 0's statistics are after phase_first: one row per pair from k_embed, per-tile partials from
 // the MFMA cross-check path
 RowStats first_stats(pf_handle* h, const ShardRun& r) {
-    return h->embed_mfma ? RowStats{r.w.spart, tiles_of(r.Lloc)} : RowStats{r.w.srow, 1};
+    return h->embed_mfma ? main_stats(r) : RowStats{r.w.srow, 1, 0};
 }
 
 // block k given its row statistics (already reduced over ranks in a site-sharded run)
@@ -759,7 +781,7 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     {
         RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag),
                      d.row_woT, d.row_bv, d.row_bo, d.col_bo,
-                     B * P, rs.nparts, (float)r.L_total};
+                     B * P, rs.nparts, (float)r.L_total, rs.flat, P, Lloc, tile_plan(P, Lloc).slots_aln};
         ProfScope ps(h, K_ROWFIN);
         hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
@@ -870,7 +892,7 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
                 if ((rc = allreduce(h, r[i].w.srow, (size_t)r[i].B * P * SROW))) return finish(rc);
             }
             if ((rc = phase_block(h, r[i], k, rs[i]))) return finish(rc);
-            rs[i] = RowStats{r[i].w.spart, tiles_of(Lloc)};
+            rs[i] = main_stats(r[i]);
         }
     for (int i = 0; i < nh; ++i) {
         h->cur = st[i];
@@ -917,6 +939,8 @@ size_t chunk_bytes(const pf_handle* h, int cb, int P, int Lloc) {
 }
 
 int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
+    // k_main counts tiles in 32 bits
+    B = (int)std::min<long>(B, std::max<long>(1, 0x7fffffffL / std::max(1, tile_plan(P, Lloc).nt_aln) - 1));
     if (B <= 1 || chunk_bytes(h, B, P, Lloc) <= (size_t)h->ws_limit_bytes) return std::max(B, 1);
     int lo = 1, hi = B;                     // largest cb in [1, B) that fits (cb = 1 always runs)
     while (hi - lo > 1) {
@@ -1404,12 +1428,12 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
     for (auto& r : runs) if ((rc = phase_first(h, r))) break;
     for (int k = 0; !rc && k < h->n_blocks; ++k) {
         for (auto& r : runs) {                                     // every rank reduces its own tiles first
-            RowStats rs = k == 0 ? first_stats(h, r) : RowStats{r.w.spart, tiles_of(r.Lloc)};
+            RowStats rs = k == 0 ? first_stats(h, r) : main_stats(r);
             if ((rc = launch_rowsum(h, r, &rs))) break;
         }
         if (rc) break;
         sum_all((size_t)B * P * SROW, false);                      // stands in for all-reduce #k
-        for (auto& r : runs) if ((rc = phase_block(h, r, k, RowStats{total, 1}))) break;
+        for (auto& r : runs) if ((rc = phase_block(h, r, k, RowStats{total, 1, 0}))) break;
     }
     if (!rc) for (auto& r : runs) if ((rc = launch_outsum(h, r))) break;
     if (!rc) {

@@ -42,12 +42,20 @@ def test_hardware_layout_selftest(engines):
 _ERRORS = {}
 
 
-def _record(case, got, want):
+def _record(case, got, want, f64=None):
     """Absolute max error of one parity case; the table is printed and, on the GPU box, written to
-    gpurun_out/parity_errors.json (copied into DESIGN.md section 5)."""
+    gpurun_out/parity_errors.json (copied into DESIGN.md section 5).  ``f64``: the same forward evaluated in
+    float64 by the oracle - the GPU's and the fp32 reference's distance from it say how much of the error is
+    the fp32 arithmetic of the comparison target itself."""
     err, scale = float(np.abs(got - want).max()), float(np.abs(want).max())
     _ERRORS[case] = {"max_abs_err": err, "max_abs_ref": scale}
-    print(f"parity {case}: max-abs error {err:.3e} (max |reference| {scale:.3g})")
+    extra = ""
+    if f64 is not None:
+        _ERRORS[case]["gpu_vs_fp64"] = float(np.abs(got - f64).max())
+        _ERRORS[case]["fp32_reference_vs_fp64"] = float(np.abs(want - f64).max())
+        extra = (f"; vs the fp64 evaluation: GPU {_ERRORS[case]['gpu_vs_fp64']:.3e}, "
+                 f"fp32 reference {_ERRORS[case]['fp32_reference_vs_fp64']:.3e}")
+    print(f"parity {case}: max-abs error {err:.3e} (max |reference| {scale:.3g}){extra}")
     try:
         import json
         os.makedirs("gpurun_out", exist_ok=True)
@@ -58,12 +66,14 @@ def _record(case, got, want):
     return err, scale
 
 
-def _bound(scale):
-    """The north star's bound is 1e-4 ABSOLUTE on distances; it is applied as such wherever the reference's
-    distances stay below 1 (every in-distribution case).  Out-of-distribution inputs (2-5 sequences, uniformly
-    random residues) drive distances to 10-40 and the reference's own fp32-vs-fp64 gap to 1e-5; there the
-    bound scales with the largest distance."""
-    return TOL * max(1.0, scale)
+def _check(err, scale, what=None):
+    """The north star's bound: 1e-4 ABSOLUTE on the distances, for every case - in distribution (errors of
+    1e-5 and below) and out of it (2-5 sequences or uniformly random residues drive distances to 5-12 and the
+    error to 9e-5 at worst; the fp32 reference itself is 1e-5 from an fp64 evaluation there, see the table).
+    A case that crosses 1e-4 is a finding about the kernels, not a tolerance to widen.  The second assertion is
+    relative and only bites where distances are small: 5e-5 of max(1, largest distance)."""
+    assert err <= TOL, (what, err)
+    assert err <= 5e-5 * max(1.0, scale), (what, err, scale)
 
 
 def test_tiny_taps_localise_every_kernel(engines, weights, golden):
@@ -104,10 +114,10 @@ def test_tiny_taps_localise_every_kernel(engines, weights, golden):
                 "max_abs_err": max(tap_rel.values()), "max_abs_ref": None,
                 "detail": {n: round(v, 9) for n, v in tap_rel.items()}}
             x_in = ref
-        # uniform-random residues incl. X and gaps drive |x| to ~130 and distances to ~12; the
-        # reference's own fp32-vs-fp64 gap is 1e-5 here, so the bound is relative (1e-4 of 12)
-        err, scale = _record("tiny_taps 5x16 random residues", d, g["dist"])
-        assert err <= _bound(scale)
+        # uniform-random residues incl. X and gaps drive |x| to ~130 and distances to ~12
+        err, scale = _record("tiny_taps 5x16 random residues", d, g["dist"],
+                             f64=O.forward(w, g["idx"], dtype=np.float64))
+        _check(err, scale, "tiny_taps")
     finally:
         e.set_option("debug_keep", 0)
 
@@ -123,10 +133,10 @@ def test_oracle_parity_small_shapes(engines, weights):
         want = O.forward_batch(w, idx)
         assert got.shape == want.shape == (2, n * (n - 1) // 2)
         # 2-5 sequences is far outside the training distribution: the residual stream reaches
-        # |x| ~ 560 and logits ~ 190 (fp32-vs-fp64 noise of the oracle itself: 5e-6), so the
-        # bound scales with the distances once they exceed 1 (absolute 1e-4 below)
-        err, scale = _record(f"oracle {n}x{l}{' gapped' if gaps else ''} pf_indel", got, want)
-        assert err <= _bound(scale), (n, l)
+        # |x| ~ 560 and logits ~ 190
+        err, scale = _record(f"oracle {n}x{l}{' gapped' if gaps else ''} pf_indel", got, want,
+                             f64=O.forward_batch(w, idx, dtype=np.float64))
+        _check(err, scale, (n, l))
 
 
 def test_oracle_parity_shapes_around_the_kernels_block_sizes(engines, weights):
@@ -141,8 +151,9 @@ def test_oracle_parity_shapes_around_the_kernels_block_sizes(engines, weights):
         idx = simulate_batch(b, n, l, seed=seed, gaps=(seed % 3 == 0))
         got = e.forward(idx)
         want = O.forward_batch(w, idx)
-        err, scale = _record(f"oracle {n}x{l} batch {b} pf", got, want)
-        assert err <= _bound(scale), (n, l, b)
+        err, scale = _record(f"oracle {n}x{l} batch {b} pf", got, want,
+                             f64=O.forward_batch(w, idx, dtype=np.float64))
+        _check(err, scale, (n, l, b))
         if b > 1:       # and the same bits one by one
             assert np.array_equal(np.stack([e.forward(x) for x in idx]), got)
 
@@ -200,7 +211,8 @@ def test_model_surface_one_hot_input_and_squeeze(weights, golden):
         assert onehot.shape == (2, 22, 40, 6)
         yb = m(onehot)
         assert yb.shape == g["dist"].shape == (2, 15)
-        err, _ = _record("model(x) one-hot batch 2 x (6x40)", yb, g["dist"])
+        err, _ = _record("model(x) one-hot batch 2 x (6x40)", yb, g["dist"],
+                         f64=O.forward_batch(weights("pf").tensors, g["idx"], dtype=np.float64))
         assert err <= TOL
         y1 = m(onehot[:1])
         assert y1.shape == (15,) and np.abs(y1 - g["dist"][0]).max() <= TOL          # B = 1 squeezes to [P]
@@ -375,3 +387,30 @@ def test_alternative_kernel_paths_agree(weights, golden):
             out[opt] = e.forward(a)
     assert np.array_equal(out[None], out["materialize_x0"])
     assert np.abs(out[None] - golden("configs.npz")["c2_dist"]).max() <= TOL
+
+
+def test_flat_tiling_against_row_tiling(weights, golden):
+    """k_main cuts an alignment's P x L tokens into 32-token tiles that may cover the end of one pair row and the
+    start of the next (flat tiling; chosen when L >= 32 and L % 32 != 0), instead of giving every row its own
+    ragged last tile.  PF_ROW_TILES=1 forces the row tiling: same distances up to the grouping of the per-row
+    partial sums (<= 2e-5 of the largest distance), for row lengths just above / below tile multiples, rows
+    shorter than two tiles, a one-row alignment, and batches whose alignments start at any token offset."""
+    from phyloformer_amd.engine import Engine
+    cases = [simulate_batch(3, 7, 33, seed=41), simulate_batch(2, 6, 63, seed=42), simulate_batch(1, 9, 65, seed=43),
+             simulate_batch(2, 2, 45, seed=44), simulate_batch(1, 14, 97, seed=45, gaps=True),
+             golden("configs.npz")["c2_idx"], simulate_batch(5, 4, 40, seed=46)]
+    for idx in cases:
+        out = {}
+        for row_tiles in (0, 1):
+            if row_tiles:
+                os.environ["PF_ROW_TILES"] = "1"
+            try:
+                with Engine(weights("pf"), 0) as e:
+                    out[row_tiles] = e.forward(idx)
+                    if not row_tiles:          # flat: an alignment's bits do not depend on its place in the batch
+                        assert np.array_equal(np.stack([e.forward(x) for x in idx]), out[0])
+                        assert np.array_equal(e.forward_shards_emulated(idx, 1), out[0])
+            finally:
+                os.environ.pop("PF_ROW_TILES", None)
+        err = np.abs(out[0] - out[1]).max()
+        assert err <= 2e-5 * max(1.0, float(np.abs(out[1]).max())), (idx.shape, err)
