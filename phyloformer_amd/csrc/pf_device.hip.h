@@ -453,18 +453,20 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 // consecutive slots part_range() names, summed in slot order by k_rowfin / k_rowsum / k_outsum.  The tiling is
 // per alignment, a function of (P, L) only: an alignment gets the same bits wherever it sits in a batch.
 struct TilePos { int b, kt, r0, l0; };   // alignment, tile inside it, row of its first token, site of that token
+template <bool FLAT>
 __device__ __forceinline__ TilePos tile_pos(const MainArgs& a, int task, int ntiles) {
     TilePos q;
     q.b = task / a.nt_aln;
     q.kt = task - q.b * a.nt_aln;
-    if (a.flat) { const int tok0 = q.kt * 32; q.r0 = tok0 / a.Lloc; q.l0 = tok0 - q.r0 * a.Lloc; }
+    if (FLAT) { const int tok0 = q.kt * 32; q.r0 = tok0 / a.Lloc; q.l0 = tok0 - q.r0 * a.Lloc; }
     else { q.r0 = q.kt / ntiles; q.l0 = (q.kt - q.r0 * ntiles) * 32; }
     return q;
 }
+template <bool FLAT>
 __device__ __forceinline__ TilePos tile_next(const MainArgs& a, TilePos q) {
     if (++q.kt == a.nt_aln) { q.b++; q.kt = 0; q.r0 = 0; q.l0 = 0; return q; }
     q.l0 += 32;
-    if (q.l0 >= a.Lloc) { q.l0 = a.flat ? q.l0 - a.Lloc : 0; q.r0++; }
+    if (q.l0 >= a.Lloc) { q.l0 = FLAT ? q.l0 - a.Lloc : 0; q.r0++; }
     return q;
 }
 // lane t of a tile: its row (inside the alignment), its site, whether it holds a token at all and whether that
@@ -475,12 +477,13 @@ __device__ __forceinline__ TilePos tile_next(const MainArgs& a, TilePos q) {
 // tile) and wrap (flat tiling: lanes from `wrap` on belong to row r0 + 1; 32 = none).  Per lane that leaves
 // one min for the clamped token offset and a compare + select for the site.
 struct LanePos { size_t tok0; int toff, l, nvalid, wrap; bool valid, in_r1; };
+template <bool FLAT>
 __device__ __forceinline__ LanePos lane_pos(const MainArgs& a, const TilePos& q, int t) {
     LanePos o;
     o.tok0 = ((size_t)q.b * a.P + q.r0) * a.Lloc + q.l0;
-    const int left = a.flat ? a.P * a.Lloc - q.kt * 32 : a.Lloc - q.l0;      // tokens from the tile's first one on
+    const int left = FLAT ? a.P * a.Lloc - q.kt * 32 : a.Lloc - q.l0;      // tokens from the tile's first one on
     o.nvalid = min(32, left);
-    o.wrap = (a.flat && q.r0 + 1 < a.P) ? min(32, a.Lloc - q.l0) : 32;
+    o.wrap = (FLAT && q.r0 + 1 < a.P) ? min(32, a.Lloc - q.l0) : 32;
     o.valid = t < o.nvalid;
     o.toff = min(t, o.nvalid - 1);
     o.in_r1 = o.toff >= o.wrap;
@@ -509,7 +512,9 @@ __device__ __forceinline__ void part_range(int flat, int pr, int nparts, int P, 
 //               fly from the 5.6 KB embedding table (L1-resident) instead of being read from HBM: x0 is
 //               never materialised (3.6 GB less written and 2 x 3.6 GB less read per batch of 16)
 //   MODE_LAST : row-apply + col-apply + FFN of the last block -> softplus head, site mean
-template <int MODE>
+//   FLAT      : the tiling (a.flat), a template parameter so that the row tiling carries none of the flat
+//               tiling's bookkeeping (shapes with L % 32 == 0, rows shorter than a tile)
+template <int MODE, bool FLAT>
 __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_frag_t lw = (lds_frag_t)smem;
@@ -561,7 +566,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         const int run = max(1, min(PF_RUN_MAX, ntasks / (nwaves * 8)));
         int run0 = (blockIdx.x * MAIN_WAVES + wave) * run;             // first tile of this wave's current run
         const int task0 = run0, task1 = ntasks;
-        TilePos cur = tile_pos(a, min(task0, ntasks - 1), ntiles);
+        TilePos cur = tile_pos<FLAT>(a, min(task0, ntasks - 1), ntiles);
         int frag_row = -1;                          // the row (b * P + p) whose row-mix fragments are in mfr
         bf16x8 mfr[4];
         // The next tile's residual rows and q' are requested when the FFN of the current tile starts
@@ -570,7 +575,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         f32x4 px[8], pctx[8], pqr, pqc;
         int pri = 0, prj = 0;                       // MODE_MID0: residues of the next tile's site in both sequences
         auto prefetch = [&](const TilePos& np) {
-            const LanePos nl = lane_pos(a, np, t);
+            const LanePos nl = lane_pos<FLAT>(a, np, t);
             const int ll = nl.l, pb = np.b;
             const size_t tk = nl.tok0 + nl.toff;
             if (MODE == MODE_MID0) {
@@ -598,13 +603,13 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             const int row = b * a.P + cur.r0;          // the tile's (first) row, counted over the batch
             // the tile that follows: the next one of this run, or the first one of the wave's next run
             int ntask = task + 1;
-            TilePos nxt = tile_next(a, cur);
+            TilePos nxt = tile_next<FLAT>(a, cur);
             if (ntask == run0 + run) {
                 run0 += nwaves * run;
                 ntask = run0;
-                if (ntask < task1) nxt = tile_pos(a, ntask, ntiles);
+                if (ntask < task1) nxt = tile_pos<FLAT>(a, ntask, ntiles);
             }
-            const LanePos lp = lane_pos(a, cur, t);
+            const LanePos lp = lane_pos<FLAT>(a, cur, t);
             // flat tiling: does this tile end row r0 and start row r0 + 1 (wave-uniform)?
             const bool straddle = lp.wrap < 32;
             int ai = 0, aj = 0;
@@ -837,7 +842,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     *reinterpret_cast<f32x4*>(a.qrow + stok * 4) = qs;
                 }
                 // one partial per row part of the tile: slot kt (+ row in flat tiling)
-                const long slot0 = (long)b * a.slots_aln + cur.kt + (a.flat ? cur.r0 : 0);
+                const long slot0 = (long)b * a.slots_aln + cur.kt + (FLAT ? cur.r0 : 0);
                 for (int part = 0; part < (straddle ? 2 : 1); ++part) {
                     float* sp = a.spart + (size_t)(slot0 + part) * SROW;
                     const float vm = (valid && lp.in_r1 == (part == 1)) ? 1.f : 0.f;
@@ -870,7 +875,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 }
                 z = pair_sum(z) + lc[CONST_HB];
                 const float spz = softplus20(z);
-                const long slot0 = (long)b * a.slots_aln + cur.kt + (a.flat ? cur.r0 : 0);
+                const long slot0 = (long)b * a.slots_aln + cur.kt + (FLAT ? cur.r0 : 0);
                 for (int part = 0; part < (straddle ? 2 : 1); ++part) {
                     const float so = half32_sum((valid && lp.in_r1 == (part == 1)) ? spz : 0.f);
                     if (lane == 0) a.outpart[slot0 + part] = so;

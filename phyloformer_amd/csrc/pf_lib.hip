@@ -671,7 +671,8 @@ int launch_main(pf_handle* h, const MainArgs& a, int kid) {
     const int cus = std::max(1, h->prop.multiProcessorCount - (h->reducing ? h->reserve_cus : 0));
     const int grid = (int)std::max<long>(1, std::min<long>(cus, (ntasks + MAIN_WAVES - 1) / MAIN_WAVES));
     ProfScope ps(h, kid);
-    hipLaunchKernelGGL(k_main<MODE>, dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->cur, a);
+    if (a.flat) hipLaunchKernelGGL((k_main<MODE, true>), dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->cur, a);
+    else hipLaunchKernelGGL((k_main<MODE, false>), dim3(grid), dim3(MAIN_THREADS), MAIN_LDS_BYTES, h->cur, a);
     HIPCHK(h, hipGetLastError());
     return PF_OK;
 }
@@ -1100,10 +1101,14 @@ static int open_device(int device, pf_handle** out) {
         // handle and before any launch, so that no launch path carries mutable state shared between handles
         // (the CLI drives two engines per GPU from two host threads).
         const struct { const void* fn; int bytes; } big_lds[] = {
-            {reinterpret_cast<const void*>(&k_main<MODE_FIRST>), MAIN_LDS_BYTES},
-            {reinterpret_cast<const void*>(&k_main<MODE_MID>), MAIN_LDS_BYTES},
-            {reinterpret_cast<const void*>(&k_main<MODE_MID0>), MAIN_LDS_BYTES},
-            {reinterpret_cast<const void*>(&k_main<MODE_LAST>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_FIRST, false>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_MID, false>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_MID0, false>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_LAST, false>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_FIRST, true>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_MID, true>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_MID0, true>), MAIN_LDS_BYTES},
+            {reinterpret_cast<const void*>(&k_main<MODE_LAST, true>), MAIN_LDS_BYTES},
             {reinterpret_cast<const void*>(&k_embed), EMBED_LDS_BYTES},
         };
         for (const auto& k : big_lds)
