@@ -466,9 +466,12 @@ def self_launch(args, argv):
     reader.start()
     while True:
         codes = [p.poll() for p in procs]
-        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
-            rc, why = 1, "rank {} exited with code {}".format(*bad[0])
+        if any(c not in (None, 0) for c in codes):
+            # a rank that dies usually takes its peers down with it (they lose the rendezvous connection):
+            # give them a moment, then name every rank that failed, not just the first one seen
+            time.sleep(0.5)
+            bad = [(r, p.poll()) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            rc, why = 1, ", ".join(f"rank {r} exited with code {c}" for r, c in bad)
             break
         if all(c == 0 for c in codes):
             break

@@ -114,7 +114,7 @@ def test_bench_self_launch_reports_a_dead_rank(tmp_path):
                       "--no-power", "--launch-timeout", "60"],
                      {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_dying_on_rank1", "TMPDIR": str(tmp_path)})
     assert res.returncode != 0 and res.stdout.strip() == ""
-    assert "rank 1 exited with code" in res.stderr
+    assert "rank 1 exited with code 7" in res.stderr
 
 
 def test_bench_self_launch_watchdog(tmp_path):
