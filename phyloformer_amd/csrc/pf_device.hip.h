@@ -1136,6 +1136,7 @@ struct ColStatsArgs {
     float* part;         // [B][G][Lloc][4*64 + 8]  out: Z~[h][c] | S_q[4] | S_k[4]
     const float* wqk;    // [8][64] folded col q (rows 0-3) and k (rows 4-7)
     const float* bqk;    // [8]
+    const float* brow;   // [64] row out_proj bias of this block (row 4 of every pair's mrow: read once, not per pair)
     int B, P, Lloc, G, nchunks;
     // Fixed two-level association of the sum over pairs: every group is cut into runs of `sub` pairs (a multiple
     // of 16; S = runs per group); a run is summed pair by pair from zero, a group is the in-order sum of its
@@ -1190,6 +1191,9 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
         }
     // after the transposing reduction lane cl holds projection cl (0-3: q', 4-7: k')
     const float bj = a.bqk[cl];
+    // the row out_proj bias is the same for every pair: eight registers instead of two of the ten 16-byte LDS
+    // reads per lane and pair (the LDS pipe is what this kernel is closest to)
+    const f32x4 br0 = *reinterpret_cast<const f32x4*>(a.brow + 8 * cl), br1 = *reinterpret_cast<const f32x4*>(a.brow + 8 * cl + 4);
     const bool up2 = (cl & 4) != 0, up1 = (cl & 2) != 0, up0 = (cl & 1) != 0;
     int bid = blockIdx.x;
     int run = 0;
@@ -1297,7 +1301,7 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
         for (int u = 0; u < 2; ++u) {
             // (for a lone last pair the second chain recomputes the first pair's matrix row: finite, unused)
             const float* m = mt + (two ? (p + u - pt) : (p - pt)) * MROW + 8 * cl;
-            f32x4 y0 = *reinterpret_cast<const f32x4*>(m + 4 * 64), y1 = *reinterpret_cast<const f32x4*>(m + 4 * 64 + 4);
+            f32x4 y0 = br0, y1 = br1;
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
                 const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + hh * 64);

@@ -788,7 +788,7 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         HIPCHK(h, hipGetLastError());
     }
     {
-        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, B, P, Lloc, w.G, (Lloc + 31) / 32,
+        ColStatsArgs a{w.x, w.qrow, w.mrow, w.qcol, w.part, d.col_wqk, d.col_bqk, d.row_bo, B, P, Lloc, w.G, (Lloc + 31) / 32,
                        w.sub, w.S, w.fine, h->table, r.d_idx, h->pair_i, h->pair_j, r.N};
         ProfScope ps(h, K_COLSTATS);
         const unsigned nblk = (unsigned)(B * a.nchunks * w.nparts());

@@ -132,3 +132,14 @@ def test_workload_label_follows_the_shape():
     assert bench.workload_label(60, 500, "pf.ckpt")[1].startswith("configs[2]")
     assert bench.workload_label(200, 500, "pf_indel.ckpt")[1].startswith("configs[4]")
     assert bench.workload_label(20, 200, "pf.ckpt")[1].startswith("configs[1]")
+
+
+def test_power_sampler_is_evidence_only():
+    """No GPU (or no librocm_smi64): the sampler turns itself off, the bench goes on; nothing is forked."""
+    sys.path.insert(0, REPO)
+    import bench
+    with bench.PowerSampler(period=0.01) as s:
+        pass
+    assert s.summary() is None or "median_w" in s.summary()
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert '"rocm-smi"' not in src and "['rocm-smi" not in src, "power is read in-process, not through the rocm-smi script"
