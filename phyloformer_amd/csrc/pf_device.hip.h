@@ -300,7 +300,7 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
     float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7];
     // not volatile: a pure function of its operands, so the scheduler may interleave the splits of
-    // independent tiles (k_main2) instead of keeping every asm statement in program order
+    // independent splits instead of keeping every asm statement in program order
     asm(
         "v_dot2c_f32_bf16 %0, %8, %10\n\tv_dot2c_f32_bf16 %1, %9, %10\n\t"
         "v_dot2c_f32_bf16 %2, %8, %11\n\tv_dot2c_f32_bf16 %3, %9, %11\n\t"
