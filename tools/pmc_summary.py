@@ -25,7 +25,8 @@ open(os.path.join(out, "pmc_summary.txt"), "w").write(txt + "\n")
 
 # HBM traffic of the dominant kernel, per token, for bench.py's roofline.traffic
 import json
-main = acc.get("void pfk::k_main<1>") or acc.get("void pfk::k_main<1>(pfk::MainArgs)")
+# k_main<MODE_MID, FLAT>: since round 3 the tiling is a template parameter; the headline shape runs <1, true>
+main = next((acc[k] for k in sorted(acc) if k.startswith("void pfk::k_main<1")), None)
 if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main and len(sys.argv) > 2:
     tokens = float(sys.argv[2])
     fetch = sum(main["FETCH_SIZE"]) / len(main["FETCH_SIZE"])
