@@ -39,7 +39,8 @@ constexpr int HD = 16;       // head_dim
 constexpr int FF = 256;      // FFN hidden
 constexpr int NA = 22;       // alphabet
 constexpr int SROW = 72;     // row statistics per pair
-constexpr int MROW = 5 * 64; // folded row mix per pair (4 heads + bias row)
+constexpr int MROW = 4 * 64; // folded row mix per pair: M[h][c], 4 heads (the bias row is the same for every pair:
+                             // k_colstats keeps it in registers, the MFMA fragments carry it in K slot 4)
 constexpr float LN_EPS = 1e-5f;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1009,7 +1010,7 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
 struct RowFinArgs {
     const float* srow;   // [B*P][nparts][72]  statistics, as nparts partial sums per pair (k_main: one per
                          //                    tile; k_embed / all-reduced: nparts = 1)
-    float* mrow;         // [B*P][5][64]   fp32 M[h][c] and the row out_proj bias (debug tap only; may be NULL)
+    float* mrow;         // [B*P][4][64]   fp32 M[h][c] (k_colstats, debug tap)
     bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments of M^T: K slots 0-3 heads, 4 the row
                          //                    out_proj bias, 5 the column out_proj bias (k_main sets both B
                          //                    slots to 1, k_colstats only slot 4)
@@ -1020,15 +1021,17 @@ struct RowFinArgs {
     int npairs, nparts;
     float L_total;
     int flat, P, Lloc, slots_aln;   // where a pair's partials are (part_range): nparts each, or k_main's flat tiling
+    int iters;           // groups of four pairs per block
 };
 
+// A block handles `iters` groups of four pairs one after the other: the 64 out_proj weights a thread holds are
+// loaded once per block, not once per four pairs - with many pairs and one partial each (a site-sharded rank:
+// 8 x the pairs, all-reduced statistics) that load was most of the kernel (1.7 ms per step at world = 8).
 __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
-    __shared__ float ctx[4][64];      // 4 pairs per block
+    __shared__ float ctx[4][64];      // 4 pairs at a time
     __shared__ float mm[4][6][64];
     __shared__ float st[4][SROW];
     const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
-    const int pr = blockIdx.x * 4 + sub;
-    const bool ok = pr < a.npairs;
     // the out_proj column of this thread first: its latency hides behind the partial sums (a lone
     // alignment's forward is a chain of 26 such latencies)
     float wo[4][16];
@@ -1037,6 +1040,9 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
 #pragma unroll
         for (int d = 0; d < 16; ++d) wo[hh][d] = a.woT[(16 * hh + d) * 64 + c];
     const float bvc = a.bv[c], biasc = a.bias[c], biascol = a.bias_col[c];
+    for (int it = 0; it < a.iters; ++it) {
+    const int pr = (blockIdx.x * a.iters + it) * 4 + sub;
+    const bool ok = pr < a.npairs;
     if (ok) {
         // partial statistics are summed in index order: the association is a function of the shape only
         long first;
@@ -1080,7 +1086,6 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
             if (m) m[hh * 64 + c] = acc;
             mm[sub][hh][c] = acc;
         }
-        if (m) m[4 * 64 + c] = biasc;
         mm[sub][4][c] = biasc;
         mm[sub][5][c] = biascol;
     }
@@ -1096,6 +1101,9 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
         bf16x8* mf = a.mfrag + (size_t)pr * MFRAG_PER_PAIR + To * 64 + t;
         mf[0] = hi;
         mf[32] = lo;
+    }
+    // (the next group's st / ctx / mm writes are ordered behind this group's reads by the barriers above:
+    // st is rewritten before the first barrier, last read before the second; ctx and mm likewise one phase on)
     }
 }
 
@@ -1131,7 +1139,7 @@ __global__ void k_outsum(const float* outpart, float* out, int npairs, int npart
 struct ColStatsArgs {
     const float* x;      // [B][P][Lloc][64]   (unused by the block-0 variant, which forms x0 from `table`)
     const float* qrow;   // [B][P][Lloc][4]
-    const float* mrow;   // [B][P][5][64]
+    const float* mrow;   // [B][P][4][64]
     float* qcol;         // [B][P][Lloc][4]  out
     float* part;         // [B][G][Lloc][4*64 + 8]  out: Z~[h][c] | S_q[4] | S_k[4]
     const float* wqk;    // [8][64] folded col q (rows 0-3) and k (rows 4-7)
@@ -1164,7 +1172,7 @@ template <bool EMBED>
 #define PF_CS_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
-    // two staging buffers of 16 pair matrices (5 x 64 floats each)
+    // two staging buffers of 16 pair matrices (4 x 64 floats each)
     __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
     __shared__ __attribute__((aligned(16))) float emb[EMBED ? 22 * 64 : 4];
     // EMBED: the group's (i, j) sequence indices, so that the residue fetch of the next pair is one dependent
@@ -1272,7 +1280,7 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
         const int n4 = min(16, p1 - pt) * (MROW / 4);
         float* dst = mst + (size_t)buf * 16 * MROW;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 16 * MROW / 4 / 256; ++k) {
             const int i = (int)threadIdx.x + 256 * k;
             __builtin_amdgcn_global_load_lds(src + min(i, n4 - 1), dst + (256 * k + 64 * wave) * 4, 16, 0, 0);
         }

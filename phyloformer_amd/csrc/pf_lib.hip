@@ -782,9 +782,13 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     {
         RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag),
                      d.row_woT, d.row_bv, d.row_bo, d.col_bo,
-                     B * P, rs.nparts, (float)r.L_total, rs.flat, P, Lloc, tile_plan(P, Lloc).slots_aln};
+                     B * P, rs.nparts, (float)r.L_total, rs.flat, P, Lloc, tile_plan(P, Lloc).slots_aln, 1};
+        // enough blocks to fill the chip a few times over (8 x 256-thread blocks per CU), each amortising its
+        // out_proj weights over `iters` groups of four pairs
+        const int groups = (B * P + 3) / 4;
+        a.iters = std::max(1, std::min(16, groups / (4 * 8 * std::max(1, h->prop.multiProcessorCount))));
         ProfScope ps(h, K_ROWFIN);
-        hipLaunchKernelGGL(k_rowfin, dim3((B * P + 3) / 4), dim3(256), 0, h->cur, a);
+        hipLaunchKernelGGL(k_rowfin, dim3((groups + a.iters - 1) / a.iters), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     {
