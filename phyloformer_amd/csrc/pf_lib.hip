@@ -522,7 +522,14 @@ struct TilePlan { int flat, nt_aln, slots_aln; };
 TilePlan tile_plan(int P, int Lloc) {
     TilePlan t;
     const int ntiles = (Lloc + 31) / 32;
-    t.flat = (Lloc >= 32 && Lloc % 32 != 0 && getenv("PF_ROW_TILES") == nullptr) ? 1 : 0;
+    // Flat tiling saves the ragged last tile of every row (a fraction `waste` of all MFMA columns) and pays for a
+    // tile over two rows - one tile per row - about a tenth of a tile (6 MFMAs, a fragment reload, a second masked
+    // reduction): worth it at L = 500 (2.3 % against 0.6 %) or 200 (10.7 % against 1.6 %), not at L = 63 (1.6 %
+    // against 5 %: a site-sharded rank at world = 8 - measured 4.33 against 4.20 ms per k_main launch) and a wash
+    // at L = 125 (4.16 against 4.15 ms).
+    const double waste = (double)(ntiles * 32 - Lloc) / (ntiles * 32), straddle = 0.10 * 32.0 / std::max(Lloc, 1);
+    t.flat = (Lloc >= 32 && waste > straddle && getenv("PF_ROW_TILES") == nullptr) ? 1 : 0;
+    if (getenv("PF_FLAT_TILES") && Lloc >= 32 && Lloc % 32 != 0) t.flat = 1;      // A/B runs
     t.nt_aln = t.flat ? (int)(((long)P * Lloc + 31) / 32) : P * ntiles;
     t.slots_aln = t.flat ? t.nt_aln + P : t.nt_aln;
     return t;

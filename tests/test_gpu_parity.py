@@ -402,8 +402,8 @@ def test_flat_tiling_against_row_tiling(weights, golden):
     for idx in cases:
         out = {}
         for row_tiles in (0, 1):
-            if row_tiles:
-                os.environ["PF_ROW_TILES"] = "1"
+            # (the host picks the tiling from the shape - flat only where it pays, e.g. not at L = 63 -: force both)
+            os.environ["PF_ROW_TILES" if row_tiles else "PF_FLAT_TILES"] = "1"
             try:
                 with Engine(weights("pf"), 0) as e:
                     out[row_tiles] = e.forward(idx)
@@ -412,5 +412,6 @@ def test_flat_tiling_against_row_tiling(weights, golden):
                         assert np.array_equal(e.forward_shards_emulated(idx, 1), out[0])
             finally:
                 os.environ.pop("PF_ROW_TILES", None)
+                os.environ.pop("PF_FLAT_TILES", None)
         err = np.abs(out[0] - out[1]).max()
         assert err <= 2e-5 * max(1.0, float(np.abs(out[1]).max())), (idx.shape, err)
