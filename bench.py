@@ -398,7 +398,8 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
                        "n_ranks_in_comm": world if comm else 0,
                        "communicators": 2 if comm else 0,
                        "collectives_per_step": round(collectives_per_step, 2),
-                       "reserve_cus": args.reserve_cus if comm else None},
+                       "reserve_cus": args.reserve_cus if comm else None,
+                       "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if comm else None},
             "value_definition": "indices resident in HBM when the timed region starts (task statement, "
                                 "Measurement: the PCIe-inclusive rate is never `value`); value_pcie_inclusive is "
                                 "the rate SURVEY.md 8d words its metric on",
@@ -528,6 +529,13 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    if world > 1 or args.force_dist:
+        # The persistent kernels leave `reserve_cus` CUs to RCCL while collectives run; a collective that wants
+        # more channels (= workgroups) than that would wait for a whole k_main launch of the other half-batch to
+        # drain.  Unless the user says otherwise, RCCL is therefore told to use at most that many channels
+        # (read by librccl when it is first loaded, i.e. before the engine resolves it).
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(1, args.reserve_cus)))
 
     # Native libraries write to file descriptor 1 as they please (RCCL prints a version banner there when a
     # communicator fails): the contract is ONE JSON line on stdout, so descriptor 1 is pointed at stderr for the
