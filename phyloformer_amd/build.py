@@ -44,13 +44,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # time, a single fragment buffer) whenever code outside the loop changes - +7 % on the loop between two builds
     # with identical loop source (round 3); the iterative ILP strategy keeps the read pairs
     # ahead of the MFMAs and is 1.3 % faster on the forward (k_colstats gains too).
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-fno-slp-vectorize", "-Wno-unused-value", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-           *SOURCES, "-o", LIB + ".tmp", "-ldl"]
+    sched = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+    base = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
+            "-fno-slp-vectorize", "-Wno-unused-value"]
+    tail = [*SOURCES, "-o", LIB + ".tmp", "-ldl"]
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        tail.append("-Rpass-analysis=kernel-resource-usage")
+    res = None
+    # the iterative-ILP strategy is a less travelled path of the compiler (it crashed on one variant of k_rowfin
+    # during round 3): if hipcc fails with it, build with the default strategy rather than not at all
+    for flags in (sched, []):
+        cmd = base + flags + tail
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode == 0:
+            break
+        if flags:
+            sys.stderr.write("phyloformer_amd.build: hipcc failed with " + " ".join(flags) +
+                             "; retrying with the default scheduling strategy\n")
     if verbose or res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
     if res.returncode != 0:
