@@ -415,3 +415,26 @@ def test_flat_tiling_against_row_tiling(weights, golden):
                 os.environ.pop("PF_FLAT_TILES", None)
         err = np.abs(out[0] - out[1]).max()
         assert err <= 2e-5 * max(1.0, float(np.abs(out[1]).max())), (idx.shape, err)
+
+
+def test_shape_sweep_against_oracle(engines, weights):
+    """Forty seeded (n_seqs, n_sites, batch) shapes - row lengths on both sides of every tile multiple up to 200, one
+    to 105 pairs, i.e. every way a 32-token tile can meet a row end or an alignment end in either tiling - against
+    the oracle (absolute 1e-4), with the same bits one alignment at a time."""
+    e = engines("pf")
+    w = weights("pf").tensors
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(2, 16)), int(rng.integers(1, 201)), int(rng.integers(1, 4))) for _ in range(32)]
+    shapes += [(3, 32, 2), (3, 64, 1), (15, 96, 2), (2, 33, 3), (11, 31, 1), (4, 160, 2), (5, 161, 1), (6, 159, 2)]
+    worst = 0.0
+    for i, (n, l, b) in enumerate(shapes):
+        idx = simulate_batch(b, n, l, seed=100 + i, gaps=(i % 4 == 0))
+        got = e.forward(idx)
+        want = O.forward_batch(w, idx)
+        err = float(np.abs(got - want).max())
+        worst = max(worst, err)
+        assert err <= TOL, (n, l, b, err)
+        if b > 1:
+            assert np.array_equal(np.stack([e.forward(x) for x in idx]), got), (n, l, b)
+    _ERRORS["shape sweep: 40 seeded shapes, 2-15 sequences x 1-200 sites (worst)"] = {"max_abs_err": worst, "max_abs_ref": None}
+    print(f"shape sweep: worst max-abs error {worst:.3e}")
