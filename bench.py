@@ -252,7 +252,19 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
 
     comm_note = None
     device = int(os.environ.get("PF_BENCH_DEVICE", local_rank))
-    eng = make_engine(device)
+    try:
+        eng = make_engine(device)
+    except ValueError as exc:
+        # more ranks than devices (e.g. `--gpus 2` tried on a 1-GPU box): share the devices round-robin instead of
+        # dying - RCCL will refuse two ranks on one device, and the ranks then agree to shard whole alignments
+        import re
+        m = re.search(r"device \d+ out of range \(have (\d+)\)", str(exc))
+        if not m or int(m.group(1)) < 1:
+            raise
+        device = local_rank % int(m.group(1))
+        comm_note = f"{world} ranks on {m.group(1)} device(s): rank {rank} shares device {device}"
+        print(f"bench: {comm_note}", file=sys.stderr)
+        eng = make_engine(device)
     comm = None
     if world > 1 or args.force_dist:
         eng.set_option("reserve_cus", args.reserve_cus)
@@ -278,7 +290,9 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
                 print(f"bench: RCCL communicator unavailable ({why}); falling back to --shard alignments",
                       file=sys.stderr)
             args.shard = "alignments"
-            comm, comm_note = None, "site-sharding unavailable (RCCL init failed), alignments sharded instead"
+            comm = None
+            comm_note = ((comm_note + "; ") if comm_note else "") + \
+                "site-sharding unavailable (RCCL init failed), alignments sharded instead"
 
     N, L = args.n_seqs, args.n_sites
     P = N * (N - 1) // 2

@@ -21,12 +21,14 @@ def _bench(argv, env_extra=None, timeout=600):
                           text=True, timeout=timeout)
 
 
-def test_bench_gpus2_self_launch_on_one_gpu_falls_back_together():
+@pytest.mark.parametrize("pin", [True, False])
+def test_bench_gpus2_self_launch_on_one_gpu_falls_back_together(pin):
     """`python3 bench.py --gpus 2`, no launcher: the parent starts two ranks, both on device 0 here
     (PF_BENCH_DEVICE=0).  RCCL refuses two ranks on one device; the ranks agree on that, destroy their
     communicators and shard whole alignments instead - one JSON line, exit code 0."""
     res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--n-seqs", "20", "--n-sites", "200",
-                  "--no-cpu-baseline", "--no-power", "--launch-timeout", "240"], {"PF_BENCH_DEVICE": "0"})
+                  "--no-cpu-baseline", "--no-power", "--launch-timeout", "240"], {"PF_BENCH_DEVICE": "0"} if pin else {})
+    # (pin = False: rank 1 asks for device 1, finds one device and shares device 0 - "2 ranks on 1 device(s)")
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
