@@ -81,3 +81,26 @@ def test_two_engines_first_forward_from_two_threads(weights, golden):
         t.join(timeout=300)
     assert not errs, errs
     assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+
+
+def test_bench_default_line_carries_the_contract():
+    """`python bench.py` as the driver runs it at N = 1 (shortened: 3 steps, no CPU baseline): ONE JSON line on
+    stdout with the contract's keys, the roofline object of the dominant kernel and every other BASELINE
+    configuration."""
+    res = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[:2000]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs", "value_pcie_inclusive"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "alignments/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "60-leaf/500-site" in d["metric"] and d["config"]["workload"].startswith("configs[2]") and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["global_batch"]) < 0.02 * d["config"]["global_batch"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["launches"] == 18
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 0.34 and r["traffic"] > 0
+    assert len(d["configs"]) == 5 and all(v["alignments_per_s"] > 0 for v in d["configs"].values())
+    assert d["value_pcie_inclusive"] <= d["value"] * 1.05
