@@ -22,6 +22,21 @@ forward, issued per half-batch on two streams / two communicators: 14 per step).
 grows -> "weak".  ``--shard alignments`` shards whole alignments instead (no collective).  The ranks meet
 through ``phyloformer_amd.rendezvous.TcpGroup`` (standard library, no torch import in a GPU rank).
 
+Fallback ladder (self-launch only): the launcher runs rung 1 = sites on two streams / two communicators; if a
+rank dies, stops making progress (``--stall-timeout``) or the rung exceeds ``--rung-timeout``, those children are
+killed and FRESH ones are started for rung 2 = ``--one-stream`` (serial collectives on one stream), then rung 3 =
+``--shard alignments`` (no collective).  A rank is never re-exec'ed.  The line records ``config.rung`` and why
+earlier rungs were abandoned.  Exit codes: 0 ok; 3 = the parity bound failed (the line is still printed, no
+further rung is tried); 4 = more ranks than GPUs without ``--allow-shared-devices``; 124 = every rung timed out.
+
+Parity (BASELINE's metric is "alignments/sec + max-abs distance error"): after the timed regions and outside them
+every rank runs the SAME entry point it timed on the reference outputs committed under ``tests/golden/`` (data
+written by oracle/gen_golden.py from the reference's CPU forward; not the oracle): configs[2] 60x500 always,
+for N > 1 also configs[3] 60x2000 with L / N sites per rank over real RCCL (and its rate, as
+``configs["configs[3] 60x2000 site-sharded xN"]``); at N = 1 all four BASELINE shapes.  The line carries
+``max_abs_err`` (worst case), ``max_abs_err_ok`` (<= 1e-4), ``ranks_bit_identical`` (CRC of every rank's result)
+and the per-case ``parity`` object.
+
 Rank 0 prints ONE JSON line (contract in the task statement).  ``value`` is the rate with the indices resident
 in HBM when the timed region starts (the task statement: the PCIe-inclusive rate "is never `value`");
 ``value_pcie_inclusive`` is the same step through ``pf_forward`` with host buffers (H2D of the indices, D2H of
@@ -34,12 +49,15 @@ op-order port of the reference on this host's cores; N = 1, rank 0 only) and ``p
 import argparse
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 import uuid
+import zlib
 
 import numpy as np
 
@@ -60,6 +78,17 @@ PMC_FILE = os.path.join("profiles", "pmc_k_main.json")
 
 # BASELINE.json configs by shape
 WORKLOADS = {(20, 200): "configs[1]", (60, 500): "configs[2]", (60, 2000): "configs[3]", (200, 500): "configs[4]"}
+
+# Parity: the reference's own outputs (tests/golden/*.npz, written by oracle/gen_golden.py from the reference's
+# CPU forward - data, not the oracle) for every BASELINE shape.  name -> (file, key prefix, checkpoint)
+PARITY_BOUND = 1e-4        # north star: max-abs distance error vs the reference CPU forward
+GOLDENS = {
+    "configs[1] 20x200 x3": ("configs.npz", "c2", "pf.ckpt"),
+    "configs[2] 60x500": ("configs.npz", "c3", "pf.ckpt"),
+    "configs[3] 60x2000": ("configs_big.npz", "c4", "pf.ckpt"),
+    "configs[4] 200x500 gapped": ("configs_big.npz", "c5", "pf_indel.ckpt"),
+}
+EXIT_PARITY, EXIT_DEVICES, EXIT_WATCHDOG = 3, 4, 124
 
 
 def parse_args(argv=None):
@@ -84,8 +113,17 @@ def parse_args(argv=None):
                          "per step) even with one rank")
     ap.add_argument("--reserve-cus", type=int, default=8,
                     help="CUs the persistent kernels leave to the RCCL kernels while collectives run")
-    ap.add_argument("--launch-timeout", type=float, default=300.0,
-                    help="self-launch (--gpus N > 1 without a launcher): seconds before the ranks are killed")
+    ap.add_argument("--rccl-max-nchannels", type=int, default=0,
+                    help="opt-in: set NCCL_MAX_NCHANNELS for the ranks (0 = leave RCCL's default; never measured at N > 1)")
+    ap.add_argument("--allow-shared-devices", action="store_true",
+                    help="let several ranks share a GPU when there are more ranks than devices (the line is then "
+                         "marked as not a scaling result); without it such a run exits with code 4")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (max_abs_err vs the committed reference outputs)")
+    ap.add_argument("--launch-timeout", type=float, default=345.0,
+                    help="self-launch (--gpus N > 1 without a launcher): seconds for all rungs of the fallback ladder together")
+    ap.add_argument("--rung-timeout", type=float, default=120.0, help="self-launch: seconds one rung of the ladder may take")
+    ap.add_argument("--stall-timeout", type=float, default=75.0,
+                    help="self-launch: a rung whose ranks report no progress for this long is abandoned")
     return ap.parse_args(argv)
 
 
@@ -149,7 +187,10 @@ class PowerSampler:
     librocm_smi64, i.e. sysfs reads; no subprocess, nothing touches the GPU queue).  Evidence only: any failure
     turns the sampler off, never the bench."""
 
-    def __init__(self, period=0.25):
+    def __init__(self, period=0.25, pci=None):
+        # pci = (domain, bus, device) of the engine's GPU: rocm_smi indexes in PCI order, HIP ordinals follow
+        # HIP_VISIBLE_DEVICES - the sampler looks the device up by address ($PF_SMI_DEVICE forces an index)
+        self._pci = pci
         self.samples, self._stop, self._period = [], threading.Event(), period
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._smi, self.joules, self.seconds = None, None, None
@@ -165,7 +206,10 @@ class PowerSampler:
     def __enter__(self):
         try:
             from phyloformer_amd.smi import Smi
-            self._smi = Smi(int(os.environ.get("PF_SMI_DEVICE", "0")))
+            forced = os.environ.get("PF_SMI_DEVICE")
+            self._smi = Smi(int(forced)) if forced is not None else Smi(0, pci=self._pci)
+            self._where = {"smi_index": self._smi.index, "pci": self._smi.bdf,
+                           "matched_by": "PF_SMI_DEVICE" if forced is not None else ("pci address of the engine's device" if self._pci else "index 0")}
             self._j0, self._t0 = self._smi.energy_j(), time.perf_counter()
             self._thread.start()
         except Exception:  # noqa: BLE001
@@ -193,6 +237,7 @@ class PowerSampler:
                "cap_w": 1400, "max_sclk_mhz": 2400, "source": "librocm_smi64 in-process during the timed regions"}
         if self.joules is not None and self.seconds:
             out["avg_w_energy_counter"] = round(self.joules / self.seconds, 1)
+        out["device"] = getattr(self, "_where", None)
         return out
 
 
@@ -224,7 +269,7 @@ def time_config(eng, n, l, B, gaps=False, budget_s=0.6):
             "frac_hbm": round(BYTES_ALG_PER_TOKEN * tok / dt / 1e12 / HBM_PEAK_TBS, 4)}
 
 
-def configs_leg(eng, make_engine_for, device):
+def configs_leg(eng, make_engine_for, device, parity=None):
     """Every other BASELINE configuration (N = 1, after the headline region; a few seconds in total):
     whole-forward roofline fractions of SURVEY.md 8d (602,240 flop and 3,328 B per token against 2.5 PFLOP/s
     and 8 TB/s; the split scheme issues three MFMA passes, so frac_mfma tops out at 1/3)."""
@@ -238,9 +283,76 @@ def configs_leg(eng, make_engine_for, device):
         e2 = make_engine_for(indel, device)
         try:
             out["configs[4] 200x500 gapped batch 2, pf_indel.ckpt"] = time_config(e2, 200, 500, 2, gaps=True)
+            if parity is not None:
+                c = parity_case(e2, "configs[4] 200x500 gapped", False, 0, 1, None)
+                if c is not None:
+                    parity["configs[4] 200x500 gapped"] = c
         finally:
             e2.close()
     return out
+
+
+def beat(stage):
+    """Progress mark for the self-launcher's stall watchdog: one line per stage in $PF_BENCH_PROGRESS/rank<r>."""
+    d = os.environ.get("PF_BENCH_PROGRESS")
+    if not d:
+        return
+    try:
+        with open(os.path.join(d, "rank" + os.environ.get("RANK", "0")), "a") as fh:
+            fh.write(f"{time.time():.3f} {stage}\n")
+    except OSError:
+        pass
+
+
+def load_golden(name):
+    """(idx uint8[b][N][L], reference distances float32[b][P], checkpoint name) or None if the file is absent."""
+    fname, key, ckpt = GOLDENS[name]
+    path = os.path.join(REPO, "tests", "golden", fname)
+    if not os.path.exists(path):
+        return None
+    with np.load(path) as g:
+        return np.ascontiguousarray(g[key + "_idx"]), np.ascontiguousarray(g[key + "_dist"]), ckpt
+
+
+def parity_case(eng, name, sharded, rank, world, group, copies=2):
+    """One committed reference output through the entry point the bench timed: ``pf_forward_sharded_device`` with
+    this rank's site range (real RCCL when the handle carries communicators) or ``pf_forward_device``.  The
+    alignment is repeated to at least ``copies`` so that both half-batches - two streams, two communicators - are
+    exercised; every copy is compared.  The ranks exchange (error, CRC32 of the result bytes) through the
+    rendezvous: in a site-sharded run every rank holds the all-reduced result, and all must hold the same bits."""
+    from phyloformer_amd import dist as pfdist
+    got = load_golden(name)
+    if got is None:
+        return None
+    idx, ref, _ = got
+    reps = max(1, -(-copies // idx.shape[0]))
+    idx, ref = np.ascontiguousarray(np.concatenate([idx] * reps)), np.concatenate([ref] * reps)
+    B, N, L = idx.shape
+    P = N * (N - 1) // 2
+    lo, hi = pfdist.site_range(L, world, rank) if sharded else (0, L)
+    local = np.ascontiguousarray(idx[:, :, lo:hi])
+    d_idx, d_out = eng.malloc(max(local.nbytes, 1)), eng.malloc(B * P * 4)
+    if local.nbytes:
+        eng.h2d(d_idx, local)
+    coll0 = eng.collective_count()
+    if sharded:
+        eng.forward_sharded_device(d_idx, B, N, lo, hi, L, d_out)
+    else:
+        eng.forward_device(d_idx, B, N, L, d_out)
+    res = np.empty((B, P), np.float32)
+    eng.d2h(res, d_out)
+    ncoll = eng.collective_count() - coll0
+    eng.free(d_idx)
+    eng.free(d_out)
+    finite = bool(np.isfinite(res).all())
+    err = float(np.abs(res - ref).max()) if finite else 1e30
+    every = group.allgather([err, zlib.crc32(res.tobytes())]) if group is not None else [[err, 0]]
+    worst = max(e for e, _ in every)
+    same = len({c for _, c in every}) == 1
+    return {"max_abs_err": worst, "max_abs_ref": round(float(np.abs(ref).max()), 4), "alignments": B,
+            "entry_point": "pf_forward_sharded_device" if sharded else "pf_forward_device",
+            "sites_per_rank": hi - lo, "collectives": ncoll, "finite": finite, "ranks_bit_identical": same,
+            "ok": bool(worst <= PARITY_BOUND and same)}
 
 
 def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdout, make_engine_for=None):
@@ -251,20 +363,43 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
     from phyloformer_amd.msa_sim import simulate_batch
 
     comm_note = None
+    beat("start")
     device = int(os.environ.get("PF_BENCH_DEVICE", local_rank))
+    eng, have = None, None
     try:
         eng = make_engine(device)
     except ValueError as exc:
-        # more ranks than devices (e.g. `--gpus 2` tried on a 1-GPU box): share the devices round-robin instead of
-        # dying - RCCL will refuse two ranks on one device, and the ranks then agree to shard whole alignments
         import re
         m = re.search(r"device \d+ out of range \(have (\d+)\)", str(exc))
-        if not m or int(m.group(1)) < 1:
+        if not m or int(m.group(1)) < 1 or world == 1:
             raise
-        device = local_rank % int(m.group(1))
-        comm_note = f"{world} ranks on {m.group(1)} device(s): rank {rank} shares device {device}"
-        print(f"bench: {comm_note}", file=sys.stderr)
-        eng = make_engine(device)
+        have = int(m.group(1))
+    n_devices = world
+    if world > 1 and group is not None:
+        # One rank per GPU is the contract.  More ranks than devices (`--gpus 8` on a smaller box used to
+        # emit a "weak scaling" number measured on shared GPUs) ends the run with its own exit code on EVERY rank -
+        # unless --allow-shared-devices, and then the line says what it is: n_gpus = distinct devices, not ranks.
+        seen = group.allgather(device if eng is not None else -1)
+        if any(d < 0 for d in seen) or len(set(seen)) < world:
+            if not args.allow_shared_devices:
+                if eng is not None:
+                    eng.close()
+                if rank == 0:
+                    print(f"bench: {world} ranks but not {world} distinct GPUs (devices asked for: {seen}, -1 = no such "
+                          "device); one rank per GPU is the contract - pass --allow-shared-devices to share them "
+                          "(the line is then marked as not a scaling result)", file=sys.stderr)
+                raise SystemExit(EXIT_DEVICES)
+            if eng is None:
+                device = local_rank % have
+                eng = make_engine(device)
+            n_devices = len(set(group.allgather(device)))
+            comm_note = (f"{world} ranks share {n_devices} device(s) (--allow-shared-devices): NOT a scaling result; "
+                         "RCCL refuses two ranks on one device, so whole alignments are sharded")
+            if rank == 0:
+                print(f"bench: {comm_note}", file=sys.stderr)
+    if eng is None:
+        raise SystemExit(f"bench: device {device} does not exist (have {have})")
+    beat("engine")
     comm = None
     if world > 1 or args.force_dist:
         eng.set_option("reserve_cus", args.reserve_cus)
@@ -294,6 +429,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
             comm_note = ((comm_note + "; ") if comm_note else "") + \
                 "site-sharding unavailable (RCCL init failed), alignments sharded instead"
 
+    beat("communicators")
     N, L = args.n_seqs, args.n_sites
     P = N * (N - 1) // 2
     if args.shard == "sites":
@@ -345,12 +481,20 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
     streams(not args.one_stream)
     for _ in range(args.warmup):
         step()
-    sampler = PowerSampler() if (rank == 0 and not args.no_power) else None
+    eng.synchronize()
+    beat("warm-up")
+    sampler = None
+    if rank == 0 and not args.no_power:
+        try:
+            sampler = PowerSampler(pci=eng.device_pci() if hasattr(eng, "device_pci") else None)
+        except Exception:  # noqa: BLE001 - evidence only
+            sampler = PowerSampler()
     if sampler:
         sampler.__enter__()
     coll0 = eng.collective_count()
     dt = timed(step, args.steps)
     collectives_per_step = (eng.collective_count() - coll0) / max(args.steps, 1)
+    beat("timed region")
     # The roofline of the dominant kernel is taken in a second timed region of the same length with the batch
     # on ONE stream: there a k_main launch has the chip to itself and covers the whole batch, so its HIP-event
     # duration is the kernel's own.  (In the two-stream schedule a half-batch launch shares the CUs with the
@@ -365,6 +509,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         prof["main"] = eng.profile_get("main")
         eng.set_option("profile", 0)
         streams(not args.one_stream)
+        beat("roofline region")
     result = np.empty((B, P), np.float32)
     eng.d2h(result, d_out)
     assert np.isfinite(result).all() and (result > 0).all()
@@ -374,9 +519,65 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
     if sampler:
         sampler.__exit__(None, None, None)
     info = eng.device_info()
+    beat("host-buffer region")
 
     total_alignments = (B if args.shard == "sites" else B * world) * args.steps
     value = total_alignments / dt
+    multi = world > 1 or args.force_dist
+    sharded = args.shard == "sites"          # the entry point the timed regions used
+    how = f"{args.shard}-sharded x{world}"
+
+    # ---- parity leg: the metric's second half, through the entry point that was timed (outside the timed regions)
+    parity = None
+    if not args.no_parity:
+        parity = {}
+        names = ["configs[2] 60x500", "configs[3] 60x2000"] if multi else \
+                ["configs[1] 20x200 x3", "configs[2] 60x500", "configs[3] 60x2000"]
+        for nm in names:
+            if GOLDENS[nm][2] != os.path.basename(args.ckpt):
+                continue                        # the goldens belong to their checkpoint
+            c = parity_case(eng, nm, sharded, rank, world, group)
+            if c is not None:
+                parity[nm] = c
+            beat("parity " + nm)
+
+    # ---- configs[3] as BASELINE words it (60 x 2000, site-sharded over the N ranks), on the N > 1 line: the same
+    # per-GPU token count as the headline batch (4 x the sites, a quarter of the alignments)
+    extra_configs = None
+    if multi and not args.no_configs:
+        n3, l3 = 60, 2000
+        p3 = n3 * (n3 - 1) // 2
+        if sharded:
+            b3 = max(2, (args.batch // 4) * world)
+            lo3, hi3 = pfdist.site_range(l3, world, rank)
+        else:
+            b3 = max(1, args.batch // 4)
+            lo3, hi3 = 0, l3
+        base3 = simulate_batch(min(b3, 4), n3, l3, seed=2 + (0 if sharded else rank))
+        idx3 = np.ascontiguousarray(base3[np.arange(b3) % base3.shape[0]][:, :, lo3:hi3])
+        d3, o3 = eng.malloc(max(idx3.nbytes, 1)), eng.malloc(b3 * p3 * 4)
+        eng.h2d(d3, idx3)
+
+        def step3():
+            if sharded:
+                eng.forward_sharded_device(d3, b3, n3, lo3, hi3, l3, o3)
+            else:
+                eng.forward_device(d3, b3, n3, l3, o3)
+
+        step3()
+        steps3 = max(2, min(args.steps, 5))
+        dt3 = timed(step3, steps3)
+        eng.free(d3)
+        eng.free(o3)
+        tot3 = (b3 if sharded else b3 * world) * steps3
+        tok3 = (b3 if sharded else b3 * world) * p3 * l3 / world        # tokens per GPU and step
+        extra_configs = {f"configs[3] 60x2000 {how}": {
+            "n_seqs": n3, "n_sites": l3, "global_batch": b3 if sharded else b3 * world,
+            "sites_per_rank": hi3 - lo3, "timed_steps": steps3, "ms_per_step": round(dt3 / steps3 * 1e3, 4),
+            "alignments_per_s": round(tot3 / dt3, 3),
+            "frac_mfma_per_gpu": round(FLOPS_ALG_PER_TOKEN * tok3 / (dt3 / steps3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+            "max_abs_err": (parity or {}).get("configs[3] 60x2000", {}).get("max_abs_err")}}
+        beat("configs[3]")
     if rank == 0:
         tokens_per_launch = B * P * (hi - lo)
         roof = None
@@ -401,19 +602,20 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         metric, workload = workload_label(N, L, args.ckpt)
         line = {
             "metric": metric,
-            "value": round(value, 3), "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 3), "unit": "alignments/s", "n_gpus": n_devices, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3-split MFMA, fp32 accumulate/residual", "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": B if args.shard == "sites" else B * world,
-                       "n_seqs": N, "n_sites": L, "parallelism": f"{args.shard}-sharded x{world}",
+                       "n_seqs": N, "n_sites": L, "parallelism": how,
                        "device": info["name"].strip(),
                        "n_ranks_in_comm": world if comm else 0,
                        "communicators": 2 if comm else 0,
                        "collectives_per_step": round(collectives_per_step, 2),
                        "reserve_cus": args.reserve_cus if comm else None,
-                       "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if comm else None},
+                       "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if comm else None,
+                       "rung": rung_info()},
             "value_definition": "indices resident in HBM when the timed region starts (task statement, "
                                 "Measurement: the PCIe-inclusive rate is never `value`); value_pcie_inclusive is "
                                 "the rate SURVEY.md 8d words its metric on",
@@ -426,19 +628,33 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
             "kernel_ms": {k: round(v[1], 3) for k, v in prof.items()} if prof else None,
             "roofline": roof,
             "power": sampler.summary() if sampler else None,
-            "configs": None,
+            "configs": extra_configs,
             "cpu_baseline": None,
         }
         if comm:
             line["config"]["rccl"] = comm
         if comm_note:
             line["config"]["note"] = comm_note
-        if world == 1 and not args.no_configs and make_engine_for is not None:
+        if n_devices != world:
+            line["n_ranks"] = world
+            line["ranks_per_device"] = round(world / n_devices, 2)
+            line["scaling_result"] = False
+        if world == 1 and not multi and not args.no_configs and make_engine_for is not None:
             eng.free(d_idx)
             eng.free(d_out)
             d_idx = d_out = None
             streams(True)
-            line["configs"] = configs_leg(eng, make_engine_for, device)
+            line["configs"] = configs_leg(eng, make_engine_for, device, parity)
+        if parity is not None:
+            errs = [c["max_abs_err"] for c in parity.values()]
+            line["max_abs_err"] = max(errs) if errs else None
+            line["max_abs_err_ok"] = bool(errs) and all(c["ok"] for c in parity.values())
+            line["ranks_bit_identical"] = all(c["ranks_bit_identical"] for c in parity.values())
+            line["parity"] = {"bound": PARITY_BOUND, "cases": parity,
+                              "reference": "outputs of the reference's CPU forward committed under tests/golden/ "
+                                           "(oracle/gen_golden.py; data, not the oracle)",
+                              "how": "after the timed regions, through the entry point that was timed; every rank "
+                                     "compares, errors and result CRCs are exchanged over the rendezvous"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
@@ -449,7 +665,13 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
     eng.close()
     if group is not None:
         group.barrier()
-    return value
+    beat("done")
+    # every rank knows every case (the allgather is symmetric): all of them report a failed bound the same way
+    parity_ok = parity is None or (len(parity) > 0 and all(c["ok"] for c in parity.values())) or \
+        (len(parity) == 0 and os.path.basename(args.ckpt) != "pf.ckpt")
+    if not parity_ok and rank == 0:
+        print(f"bench: PARITY FAILED: {json.dumps(parity)}", file=sys.stderr)
+    return value, parity_ok
 
 
 # ---- self-launch: `python3 bench.py --gpus N` without a launcher -------------------------------------------
@@ -461,24 +683,76 @@ def free_port():
     return port
 
 
-def self_launch(args, argv):
-    """Parent of N ranks.  Touches neither HIP nor the engine: it only starts fresh children of this script,
-    one per GPU, and waits.  Rank 0's stdout (the JSON line) is relayed; every child's stderr is inherited.
-    Returns the exit code: 0 only if every rank exited 0 within ``--launch-timeout`` seconds."""
-    world = args.gpus
+# The fallback ladder of a self-launched N > 1 run: (name, extra arguments for the ranks).
+RUNGS = [("sites, two streams / two communicators", []),
+         ("sites, one stream (serial collectives)", ["--one-stream"]),
+         ("whole alignments per rank, no collective", ["--shard", "alignments"])]
+
+
+def ladder(args):
+    if args.shard == "alignments":
+        return RUNGS[2:]
+    return RUNGS[1:] if args.one_stream else RUNGS
+
+
+def rung_info():
+    """What the launcher told this rank about the ladder (config.rung of the line); None outside a self-launch."""
+    if "PF_BENCH_RUNG" not in os.environ:
+        return None
+    try:
+        return {"index": int(os.environ["PF_BENCH_RUNG"]), "name": os.environ.get("PF_BENCH_RUNG_NAME", ""),
+                "abandoned": json.loads(os.environ.get("PF_BENCH_RUNG_HISTORY", "[]"))}
+    except ValueError:
+        return None
+
+
+def launch_rung(args, argv, world, index, name, history, deadline):
+    """One rung: N fresh children of this script, one per GPU.  Returns (rc, why, rank 0's stdout).  rc 0 only if
+    every rank exited 0 before the rung's limits: ``--rung-timeout`` seconds in total, ``--stall-timeout`` seconds
+    without a progress mark from any rank (bench.beat), the launch's overall ``deadline``."""
     env = dict(os.environ)
+    progress = tempfile.mkdtemp(prefix="pf_bench_progress_")
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the GPU pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's
+    # intra-node transport setup fails with "hipIpcGetMemHandle: invalid argument" (task statement, Environment).
+    # It is already exported on the boxes; the launcher pins it for its children in case a wrapper dropped it.
     env.update({"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
-                "PF_RUN_ID": uuid.uuid4().hex, "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                "PF_RUN_ID": uuid.uuid4().hex, "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                "PF_BENCH_RUNG": str(index), "PF_BENCH_RUNG_NAME": name, "PF_BENCH_RUNG_HISTORY": json.dumps(history),
+                "PF_BENCH_PROGRESS": progress})
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    deadline = time.monotonic() + args.launch_timeout
+    t_start = time.monotonic()
+    rung_deadline = min(deadline, t_start + args.rung_timeout)
     rc, why = 0, ""
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    marks, last_progress = {}, t_start
+
+    def progress_seen():
+        nonlocal last_progress
+        for r in range(world):
+            try:
+                sz = os.path.getsize(os.path.join(progress, f"rank{r}"))
+            except OSError:
+                sz = 0
+            if marks.get(r) != sz:
+                marks[r] = sz
+                last_progress = time.monotonic()
+
+    def where():
+        out = []
+        for r in range(world):
+            try:
+                with open(os.path.join(progress, f"rank{r}")) as fh:
+                    out.append(f"rank {r}: " + (fh.read().strip().splitlines() or ["-"])[-1].split(" ", 1)[-1])
+            except OSError:
+                out.append(f"rank {r}: no progress mark")
+        return "; ".join(out)
+
     while True:
         codes = [p.poll() for p in procs]
         if any(c not in (None, 0) for c in codes):
@@ -486,12 +760,18 @@ def self_launch(args, argv):
             # give them a moment, then name every rank that failed, not just the first one seen
             time.sleep(0.5)
             bad = [(r, p.poll()) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            rc, why = 1, ", ".join(f"rank {r} exited with code {c}" for r, c in bad)
+            rc = bad[0][1] if all(c == bad[0][1] for _, c in bad) and bad[0][1] in (EXIT_PARITY, EXIT_DEVICES) else 1
+            why = ", ".join(f"rank {r} exited with code {c}" for r, c in bad)
             break
         if all(c == 0 for c in codes):
             break
-        if time.monotonic() > deadline:
-            rc, why = 124, f"watchdog: ranks still running after {args.launch_timeout:.0f} s"
+        now = time.monotonic()
+        progress_seen()
+        if now > rung_deadline:
+            rc, why = EXIT_WATCHDOG, f"watchdog: ranks still running after {now - t_start:.0f} s ({where()})"
+            break
+        if now - last_progress > args.stall_timeout:
+            rc, why = EXIT_WATCHDOG, f"watchdog: no progress from any rank for {args.stall_timeout:.0f} s ({where()})"
             break
         time.sleep(0.05)
     if rc:
@@ -505,15 +785,42 @@ def self_launch(args, argv):
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
-        print(f"bench: {why}; all {world} ranks stopped", file=sys.stderr)
+        print(f"bench: rung {index} ({name}): {why}; all {world} ranks stopped", file=sys.stderr)
     reader.join(timeout=5)
-    text = (out0[0] if out0 else b"").decode(errors="replace")
+    shutil.rmtree(progress, ignore_errors=True)
+    return rc, why, (out0[0] if out0 else b"").decode(errors="replace")
+
+
+def self_launch(args, argv):
+    """Parent of the ranks.  Touches neither HIP nor the engine: it only starts fresh children of this script, one
+    per GPU, and waits.  Rank 0's stdout (the JSON line) is relayed; every child's stderr is inherited.  A rung
+    that loses a rank or stalls is abandoned - its children are killed by PID - and the next rung of the ladder
+    starts FRESH children (a hung collective cannot be recovered inside its processes, and a rank that has
+    touched the GPU must never exec).  Returns 0 if some rung produced the line with every rank exiting 0."""
+    world = args.gpus
+    deadline = time.monotonic() + args.launch_timeout
+    history, rc, text = [], 1, ""
+    rungs = ladder(args)
+    first = len(RUNGS) - len(rungs) + 1             # rungs are numbered 1..3 whatever subset runs
+    for index, (name, extra) in enumerate(rungs, start=first):
+        if index > first and time.monotonic() + 15 > deadline:
+            print("bench: no time left for another rung", file=sys.stderr)
+            break
+        rc, why, text = launch_rung(args, list(argv) + extra, world, index, name, history, deadline)
+        if rc == 0 and text.strip():
+            break
+        if rc == 0:
+            rc, why = 1, "rank 0 printed nothing"
+            print(f"bench: rung {index}: {why}", file=sys.stderr)
+        if rc in (EXIT_PARITY, EXIT_DEVICES):
+            break           # a result that fails its bound, or a box without the GPUs: another schedule changes neither
+        history.append({"rung": index, "name": name, "why": why})
+        text = ""
     if text:
         sys.stdout.write(text)
         sys.stdout.flush()
-    if rc == 0 and not text.strip():
-        print("bench: rank 0 printed nothing", file=sys.stderr)
-        rc = 1
+    if rc and history and rc not in (EXIT_PARITY, EXIT_DEVICES):
+        rc = EXIT_WATCHDOG if all("watchdog" in h["why"] for h in history) else 1
     return rc
 
 
@@ -544,12 +851,11 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
-    if world > 1 or args.force_dist:
-        # The persistent kernels leave `reserve_cus` CUs to RCCL while collectives run; a collective that wants
-        # more channels (= workgroups) than that would wait for a whole k_main launch of the other half-batch to
-        # drain.  Unless the user says otherwise, RCCL is therefore told to use at most that many channels
-        # (read by librccl when it is first loaded, i.e. before the engine resolves it).
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(1, args.reserve_cus)))
+    if (world > 1 or args.force_dist) and args.rccl_max_nchannels > 0:
+        # Opt-in only: a channel cap has never been measured at N > 1, and RCCL's channels are
+        # independent workgroups - those that find no free CU next to the persistent kernels wait for the end of
+        # a k_main launch (<= 4 ms), they do not deadlock.  Read by librccl when it is first loaded.
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_nchannels)
 
     # Native libraries write to file descriptor 1 as they please (RCCL prints a version banner there when a
     # communicator fails): the contract is ONE JSON line on stdout, so descriptor 1 is pointed at stderr for the
@@ -561,13 +867,14 @@ def main(argv=None):
     from phyloformer_amd.rendezvous import TcpGroup
     w, make_engine, make_engine_for = engine_factories(args.ckpt)
     group = TcpGroup(rank, world) if (world > 1 or args.force_dist) else None
+    ok = True
     try:
-        run(args, rank, world, local_rank, group, make_engine, w, out=line_out, make_engine_for=make_engine_for)
+        _value, ok = run(args, rank, world, local_rank, group, make_engine, w, out=line_out, make_engine_for=make_engine_for)
     finally:
         if group is not None:
             group.close()
         line_out.flush()
-    return 0
+    return 0 if ok else EXIT_PARITY
 
 
 if __name__ == "__main__":

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2
+#define PF_ABI_VERSION 3
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -123,7 +123,13 @@ int pf_forward(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N, int32_t
 
 /* Same with device-resident buffers, asynchronous on the handle's stream
  * (used by the benchmark so the timed region starts with inputs in HBM).
- * d_idx: device uint8 [B][N][L]; d_out: device float [B][P]. */
+ * d_idx: device uint8 [B][N][L]; d_out: device float [B][P].
+ * Residues are NOT validated on this path (the bytes never pass through the host).  A byte > 21 cannot
+ * fault: every table lookup of the kernels clamps it to 21 ('-').  It is reported late: the embedding
+ * kernel raises a sticky flag on the handle, and the next pf_synchronize / pf_memcpy_d2h on it returns
+ * PF_EINVAL once (the results of the forwards since the previous synchronisation are then those of the
+ * clamped alignment, not of a valid one).  pf_forward / pf_forward_sharded keep refusing such input up
+ * front (the reference raises KeyError, phyloformer/data.py:25-26). */
 int pf_forward_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N, int32_t L,
                       float* d_out);
 
@@ -139,6 +145,9 @@ int pf_forward_sharded(pf_handle_t* h, const uint8_t* idx, int32_t B, int32_t N,
                        int32_t l_begin, int32_t l_end, int32_t L_total, float* out);
 int pf_forward_sharded_device(pf_handle_t* h, const uint8_t* d_idx, int32_t B, int32_t N,
                               int32_t l_begin, int32_t l_end, int32_t L_total, float* d_out);
+/* A rank without sites (L_total < world size: l_begin == l_end, idx may be NULL) still calls
+ * pf_forward_sharded*: it joins every collective of its peers with zeros, cut into the same chunks and
+ * halves.  On a handle that does not communicate an empty range is PF_EINVAL like any L < 1. */
 
 /* RCCL bootstrap (one process per GPU).  Rank 0 calls pf_comm_unique_id and
  * ships the PF_UNIQUE_ID_BYTES bytes to the other ranks by any means
@@ -183,6 +192,9 @@ int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap)
 /* Device properties the benchmark prints: name, CU count, HBM bytes. */
 int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_count,
                    uint64_t* hbm_bytes);
+/* PCI address of the handle's device (hipDeviceProp_t pciDomainID / pciBusID / pciDeviceID), so that a caller
+ * can find the same GPU in tools that index in PCI order (rocm_smi) whatever HIP_VISIBLE_DEVICES says. */
+int pf_device_pci(pf_handle_t* h, int32_t* domain, int32_t* bus, int32_t* device);
 
 /* Single-GPU emulation of pf_forward_sharded over `nshards` ranks (test backend): same kernels
  * and per-shard workspaces as real ranks, the RCCL all-reduces replaced by device-side sums.

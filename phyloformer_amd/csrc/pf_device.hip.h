@@ -5,7 +5,7 @@
 //   qrow  [B][P][Lloc][4]    q' = elu(q)+1 of the row attention of the next block to run
 //   qcol  [B][P][Lloc][4]    q' of the column attention of the current block
 //   srow  [B][P][72]         row statistics: S_kv[64] (no v-bias) | S_q[4] | S_k[4]
-//   mrow  [B][P][5][64]      folded row mix  M[h][c] (h<4) and bias row (h=4)
+//   mrow  [B][P][4][64]      folded row mix  M[h][c], 4 heads (the bias row, equal for every pair, is not stored)
 //   ctx   [B][Lloc][64]      column context ctx[h*16+d], normalised
 //
 // Algebra (reference: phyloformer/attention.py:160-197, model.py:87-106).  With
@@ -77,6 +77,11 @@ constexpr int MAIN_THREADS = 512;  // 8 waves: two per SIMD so MFMA and VALU pha
 constexpr int MAIN_WAVES = MAIN_THREADS / 64;
 
 __device__ __forceinline__ int kmap(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+// Residue bytes index 22-row tables.  The host entry points refuse a byte > 21 (PF_EINVAL, data.py:25-26 raises
+// KeyError there); the device entry points take buffers the library has never seen, so every table lookup clamps:
+// an out-of-alphabet byte reads row 21 ('-') instead of up to 60 KB past a 5.6 KB table, and k_embed raises the
+// handle's sticky flag so that the next synchronising call reports PF_EINVAL (include/phyloformer_amd.h).
+__device__ __forceinline__ int residue(int r) { return min(r, NA - 1); }
 
 // ---- cross-lane helpers -----------------------------------------------------------------
 // v_permlane32_swap(vdst=v, src=v): r[0] = value of lane (l & 31), r[1] = value of lane 32 + (l & 31).
@@ -582,8 +587,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             if (MODE == MODE_MID0) {
                 const uint8_t* ib = a.idx + (size_t)pb * a.N * a.Lloc + ll;
                 const int pp = np.r0 + (nl.in_r1 ? 1 : 0);
-                pri = ib[(size_t)a.pair_i[pp] * a.Lloc];
-                prj = ib[(size_t)a.pair_j[pp] * a.Lloc];
+                pri = residue(ib[(size_t)a.pair_i[pp] * a.Lloc]);
+                prj = residue(ib[(size_t)a.pair_j[pp] * a.Lloc]);
             } else {
                 const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + tk * 64 + 4 * h);
 #pragma unroll
@@ -630,8 +635,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 
             if (MODE == MODE_FIRST) {
                 // embedding lookup + pair expansion (model.py:173-175): x = T[a_i] + T[a_j]
-                const int ri = a.idx[((size_t)b * a.N + ai) * a.Lloc + lc_];
-                const int rj = a.idx[((size_t)b * a.N + aj) * a.Lloc + lc_];
+                const int ri = residue(a.idx[((size_t)b * a.N + ai) * a.Lloc + lc_]);
+                const int rj = residue(a.idx[((size_t)b * a.N + aj) * a.Lloc + lc_]);
                 const f32x4* ti = reinterpret_cast<const f32x4*>(a.table + ri * 64 + 4 * h);
                 const f32x4* tj = reinterpret_cast<const f32x4*>(a.table + rj * 64 + 4 * h);
 #pragma unroll
@@ -923,6 +928,7 @@ struct EmbedArgs {
     float* qrow;             // [B*P][Lloc][4]
     float* srow;             // [B*P][72]
     int B, N, P, Lloc;
+    unsigned* bad_idx;       // host-mapped sticky flag: set when a residue byte > 21 is seen (then clamped to 21)
 };
 
 __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
@@ -953,9 +959,12 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
         // at ~480 cycles per four sites.  Same sites per lane in the same order: same sums.
         // (what travels is the row number of the residue pair in the table: one multiply-add per site instead
         // of one per lane and iteration)
+        bool bad = false;
         auto fetch = [&](int blk) {
             const int l = min(blk * 64 + lane, a.Lloc - 1);
-            return (int)ri[l] * 22 + (int)rj[l];
+            const int ra = ri[l], rb = rj[l];
+            bad |= max(ra, rb) >= NA;
+            return residue(ra) * 22 + residue(rb);
         };
         const int nblk = (a.Lloc + 63) >> 6;
         int cur = fetch(0);
@@ -1003,6 +1012,7 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
             *reinterpret_cast<f32x4*>(sr + 4 * cl) = acc;
             if (cl < 2) *reinterpret_cast<f32x4*>(sr + 64 + 4 * cl) = acce;
         }
+        if (bad && a.bad_idx) *a.bad_idx = 1u;      // (never taken on valid input; plain store, any writer wins)
     }
 }
 
@@ -1261,8 +1271,8 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
         const int pl = min(pc, p1 - 1) - p0;                  // the prefetch past the group's end is never used
         const int si = pij_lds ? (int)pij[pl] : (int)a.pair_i[pc];
         const int sj = pij_lds ? (int)pij[PIJ_CAP + pl] : (int)a.pair_j[pc];
-        nri[u] = ib[(size_t)si * a.Lloc];
-        nrj[u] = ib[(size_t)sj * a.Lloc];
+        nri[u] = residue(ib[(size_t)si * a.Lloc]);
+        nrj[u] = residue(ib[(size_t)sj * a.Lloc]);
     };
     auto lookup = [&](int u) {
         const float* ei = emb + nri[u] * 64 + 8 * cl;

@@ -280,6 +280,11 @@ struct pf_handle {
     double prof_ms[K_COUNT] = {0};
     // debug taps
     std::map<std::string, std::vector<float>> taps;
+    // A/B runs: PF_ROW_TILES / PF_FLAT_TILES, read once at creation (-1 = choose from the shape)
+    int tile_force = -1;
+    // sticky "residue byte > 21 seen" flag: pinned host memory the kernels write through its device alias
+    unsigned* bad_idx_host = nullptr;
+    unsigned* bad_idx_dev = nullptr;
 };
 
 namespace {
@@ -519,7 +524,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // start of the next - whenever rows are at least one tile long and not a whole number of tiles; otherwise every
 // row has its own ceil(Lloc / 32) tiles.
 struct TilePlan { int flat, nt_aln, slots_aln; };
-TilePlan tile_plan(int P, int Lloc) {
+TilePlan tile_plan(const pf_handle* h, int P, int Lloc) {
     TilePlan t;
     const int ntiles = (Lloc + 31) / 32;
     // Flat tiling saves the ragged last tile of every row (a fraction `waste` of all MFMA columns) and pays for a
@@ -528,8 +533,8 @@ TilePlan tile_plan(int P, int Lloc) {
     // against 5 %: a site-sharded rank at world = 8 - measured 4.33 against 4.20 ms per k_main launch) and a wash
     // at L = 125 (4.16 against 4.15 ms).
     const double waste = (double)(ntiles * 32 - Lloc) / (ntiles * 32), straddle = 0.10 * 32.0 / std::max(Lloc, 1);
-    t.flat = (Lloc >= 32 && waste > straddle && getenv("PF_ROW_TILES") == nullptr) ? 1 : 0;
-    if (getenv("PF_FLAT_TILES") && Lloc >= 32 && Lloc % 32 != 0) t.flat = 1;      // A/B runs
+    t.flat = (Lloc >= 32 && waste > straddle && h->tile_force != 0) ? 1 : 0;
+    if (h->tile_force == 1 && Lloc >= 32 && Lloc % 32 != 0) t.flat = 1;      // A/B runs (PF_FLAT_TILES)
     t.nt_aln = t.flat ? (int)(((long)P * Lloc + 31) / 32) : P * ntiles;
     t.slots_aln = t.flat ? t.nt_aln + P : t.nt_aln;
     return t;
@@ -577,7 +582,7 @@ void colstats_plan(const pf_handle* h, int B, int P, int Lloc, Workspace* w) {
     w->fine = h->colstats_fine < 0 ? (int)auto_fine : (h->colstats_fine && w->S > 1);
 }
 
-size_t workspace_bytes(int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) {
+size_t workspace_bytes(const pf_handle* h, int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) {
     const size_t tok = (size_t)B * P * Lloc;
     size_t o = 0;
     off[0] = o; o = align_up(o + (tok + 32) * 64 * 4, 256);              // x (+ 32-token trash area)
@@ -588,7 +593,7 @@ size_t workspace_bytes(int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) 
     off[5] = o; o = align_up(o + (size_t)B * nparts * Lloc * CPART * 4, 256); // part
     off[6] = o; o = align_up(o + (size_t)B * Lloc * 64 * 4, 256);        // ctx
     off[7] = o; o = align_up(o + (size_t)B * P * MFRAG_PER_PAIR * 16, 256); // mfrag
-    const size_t slots = (size_t)tile_plan(P, Lloc).slots_aln;
+    const size_t slots = (size_t)tile_plan(h, P, Lloc).slots_aln;
     off[8] = o; o = align_up(o + (size_t)B * slots * SROW * 4, 256);   // spart: row statistics per tile part
     off[9] = o; o = align_up(o + (size_t)B * slots * 4, 256);          // outpart: head sums per tile part
     return o;
@@ -597,7 +602,7 @@ size_t workspace_bytes(int B, int P, int Lloc, int nparts, size_t off[WS_BUFS]) 
 int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w, bool second = false) {
     size_t off[WS_BUFS];
     colstats_plan(h, B, P, Lloc, w);
-    const size_t need = workspace_bytes(B, P, Lloc, w->nparts(), off);
+    const size_t need = workspace_bytes(h, B, P, Lloc, w->nparts(), off);
     char*& ws = second ? h->ws2 : h->ws;
     size_t& have = second ? h->ws2_bytes : h->ws_bytes;
     if (need > have) {
@@ -690,6 +695,7 @@ struct ShardRun {
     const uint8_t* d_idx;
     float* d_out;
     int B, N, P, Lloc, L_total;
+    TilePlan tp;       // k_main's tiling of (P, Lloc), computed once per run
 };
 
 MainArgs main_args(pf_handle* h, const ShardRun& r) {
@@ -698,8 +704,7 @@ MainArgs main_args(pf_handle* h, const ShardRun& r) {
     m.mfrag = reinterpret_cast<const bf16x8*>(r.w.mfrag); m.ctx = r.w.ctx; m.spart = r.w.spart;
     m.outpart = r.w.outpart; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
     m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc;
-    const TilePlan tp = tile_plan(r.P, r.Lloc);
-    m.flat = tp.flat; m.nt_aln = tp.nt_aln; m.slots_aln = tp.slots_aln;
+    m.flat = r.tp.flat; m.nt_aln = r.tp.nt_aln; m.slots_aln = r.tp.slots_aln;
     m.store_x_last = h->debug_keep ? 1 : 0;
     m.trash_tok = (size_t)r.B * r.P * r.Lloc;
     m.ablate = h->ablate;
@@ -726,7 +731,7 @@ int phase_first(pf_handle* h, const ShardRun& r) {
         // x0 is written only for those who read it: the round-1 consumers or the "x0" debug tap
         float* x0 = (x0_on_the_fly(h) && !h->debug_keep) ? nullptr : r.w.x;
         EmbedArgs e{r.d_idx, h->pair_i, h->pair_j, h->pair_table, h->table, x0, r.w.qrow, r.w.srow,
-                    r.B, r.N, r.P, r.Lloc};
+                    r.B, r.N, r.P, r.Lloc, h->bad_idx_dev};
         const int ntasks = r.B * r.P, wpb = EMBED_THREADS / 64;
         const int grid = std::max(1, std::min(h->prop.multiProcessorCount, (ntasks + wpb - 1) / wpb));
         ProfScope ps(h, K_EMBED);
@@ -750,7 +755,7 @@ int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
     const int n = r.B * r.P * SROW;
     ProfScope ps(h, K_ROWFIN);
     hipLaunchKernelGGL(k_rowsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, rs->p, r.w.srow, r.B * r.P, rs->nparts,
-                       rs->flat, r.P, r.Lloc, tile_plan(r.P, r.Lloc).slots_aln);
+                       rs->flat, r.P, r.Lloc, r.tp.slots_aln);
     HIPCHK(h, hipGetLastError());
     *rs = RowStats{r.w.srow, 1, 0};
     return PF_OK;
@@ -760,7 +765,7 @@ int launch_rowsum(pf_handle* h, const ShardRun& r, RowStats* rs) {
 int launch_outsum(pf_handle* h, const ShardRun& r) {
     const int n = r.B * r.P;
     ProfScope ps(h, K_ROWFIN);
-    const TilePlan tp = tile_plan(r.P, r.Lloc);
+    const TilePlan& tp = r.tp;
     hipLaunchKernelGGL(k_outsum, dim3((n + 255) / 256), dim3(256), 0, h->cur, r.w.outpart, r.d_out, n,
                        tiles_of(r.Lloc), 1.0f / (float)r.L_total, tp.flat, r.P, r.Lloc, tp.slots_aln);
     HIPCHK(h, hipGetLastError());
@@ -768,7 +773,7 @@ int launch_outsum(pf_handle* h, const ShardRun& r) {
 }
 
 // the per-part statistics a k_main launch leaves in spart
-RowStats main_stats(const ShardRun& r) { return RowStats{r.w.spart, tiles_of(r.Lloc), tile_plan(r.P, r.Lloc).flat}; }
+RowStats main_stats(const ShardRun& r) { return RowStats{r.w.spart, tiles_of(r.Lloc), r.tp.flat}; }
 
 // where block 0's statistics are after phase_first: one row per pair from k_embed, per-tile partials from
 // the MFMA cross-check path
@@ -789,7 +794,7 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
     {
         RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag),
                      d.row_woT, d.row_bv, d.row_bo, d.col_bo,
-                     B * P, rs.nparts, (float)r.L_total, rs.flat, P, Lloc, tile_plan(P, Lloc).slots_aln, 1};
+                     B * P, rs.nparts, (float)r.L_total, rs.flat, P, Lloc, r.tp.slots_aln, 1};
         // enough blocks to fill the chip a few times over (8 x 256-thread blocks per CU), each amortising its
         // out_proj weights over `iters` groups of four pairs
         const int groups = (B * P + 3) / 4;
@@ -838,6 +843,9 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
 // one batch chunk, everything resident on the device
 // Does this forward issue collectives?  Only the site-sharded entry points on a handle with a communicator.
 bool reduces_now(const pf_handle* h) { return h->sharded_call && (h->world > 1 || h->comm[0]); }
+// A site-sharded call for an empty site range on a handle whose forward communicates: the rank holds no token
+// but must still join every collective of its peers.
+bool empty_rank_call(const pf_handle* h, int Lloc) { return Lloc == 0 && reduces_now(h); }
 
 // How a chunk of B alignments is cut for the overlapped schedule: two halves when collectives run.  Every
 // rank must cut identically (one all-reduce sequence per half), so this depends on B and the options only.
@@ -854,6 +862,14 @@ int ensure_second_stream(pf_handle* h) {
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     return PF_OK;
 }
+
+// Whatever way a forward leaves - a HIPCHK return included - the handle goes back to its main stream and stops
+// reserving CUs for collectives (an early return used to leave `reducing` / `cur` set).
+struct ForwardScope {
+    pf_handle* h;
+    ForwardScope(pf_handle* h_, bool reduces) : h(h_) { h->reducing = reduces; }
+    ~ForwardScope() { h->cur = h->stream; h->reducing = false; }
+};
 
 // One batch chunk, everything resident on the device.
 // Site-sharded runs with >= 2 alignments are cut into two half-batches on two streams: the all-reduce of one
@@ -876,46 +892,42 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
         const int nb = (nh == 2) ? (i == 0 ? (B + 1) / 2 : B / 2) : B;
         r[i].d_idx = d_idx + (size_t)b0 * N * Lloc; r[i].d_out = d_out + (size_t)b0 * P;
         r[i].B = nb; r[i].N = N; r[i].P = P; r[i].Lloc = Lloc; r[i].L_total = L_total;
+        r[i].tp = tile_plan(h, P, Lloc);
         if ((rc = ensure_workspace(h, nb, P, Lloc, &r[i].w, i == 1))) return rc;
         b0 += nb;
     }
+    ForwardScope scope(h, reduces);
     if (nh == 2) {
         if ((rc = ensure_second_stream(h))) return rc;
         st[1] = h->stream2;
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));          // inputs were produced on the main stream
         HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     }
-    h->reducing = reduces;
-    auto finish = [&](int code) {
-        h->cur = h->stream;
-        h->reducing = false;
-        return code;
-    };
     for (int i = 0; i < nh; ++i) {
         h->cur = st[i];
-        if ((rc = phase_first(h, r[i]))) return finish(rc);
+        if ((rc = phase_first(h, r[i]))) return rc;
         rs[i] = first_stats(h, r[i]);
     }
     for (int k = 0; k < h->n_blocks; ++k)
         for (int i = 0; i < nh; ++i) {
             h->cur = st[i];
             if (reduces) {                                                 // site-sharded runs only
-                if ((rc = launch_rowsum(h, r[i], &rs[i]))) return finish(rc);
-                if ((rc = allreduce(h, r[i].w.srow, (size_t)r[i].B * P * SROW))) return finish(rc);
+                if ((rc = launch_rowsum(h, r[i], &rs[i]))) return rc;
+                if ((rc = allreduce(h, r[i].w.srow, (size_t)r[i].B * P * SROW))) return rc;
             }
-            if ((rc = phase_block(h, r[i], k, rs[i]))) return finish(rc);
+            if ((rc = phase_block(h, r[i], k, rs[i]))) return rc;
             rs[i] = main_stats(r[i]);
         }
     for (int i = 0; i < nh; ++i) {
         h->cur = st[i];
-        if ((rc = launch_outsum(h, r[i]))) return finish(rc);
-        if ((rc = allreduce(h, r[i].d_out, (size_t)r[i].B * P))) return finish(rc);
+        if ((rc = launch_outsum(h, r[i]))) return rc;
+        if ((rc = allreduce(h, r[i].d_out, (size_t)r[i].B * P))) return rc;
     }
     if (nh == 2) {
         HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));         // the caller continues on the main stream
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
-    return finish(PF_OK);
+    return PF_OK;
 }
 
 int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
@@ -945,14 +957,14 @@ size_t chunk_bytes(const pf_handle* h, int cb, int P, int Lloc) {
         if (nb < 1) continue;
         Workspace w;
         colstats_plan(h, nb, P, Lloc, &w);
-        total += workspace_bytes(nb, P, Lloc, w.nparts(), off);
+        total += workspace_bytes(h, nb, P, Lloc, w.nparts(), off);
     }
     return total;
 }
 
 int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
     // k_main counts tiles in 32 bits
-    B = (int)std::min<long>(B, std::max<long>(1, 0x7fffffffL / std::max(1, tile_plan(P, Lloc).nt_aln) - 1));
+    B = (int)std::min<long>(B, std::max<long>(1, 0x7fffffffL / std::max(1, tile_plan(h, P, Lloc).nt_aln) - 1));
     if (B <= 1 || chunk_bytes(h, B, P, Lloc) <= (size_t)h->ws_limit_bytes) return std::max(B, 1);
     int lo = 1, hi = B;                     // largest cb in [1, B) that fits (cb = 1 always runs)
     while (hi - lo > 1) {
@@ -980,27 +992,28 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
         // a partial site range without a communicator would return partial sums divided by L_total
         return fail(h, PF_ESTATE, "site range [%d, %d) of %d needs a communicator (pf_comm_init) to be reduced",
                     l_begin, l_end, L_total);
-    if (h && Lloc == 0 && h->world > 1 && B >= 1 && N >= 2 && L_total >= 1) {
+    if (h && empty_rank_call(h, Lloc) && B >= 1 && N >= 2 && L_total >= 1) {
         // A rank that owns no sites (L_total < world) still joins every collective with zeros: the same
         // chunks, the same halves on the same two streams / communicators and the same counts as its peers
-        // issue (forward_chunk).
+        // issue (forward_chunk).  (A single-rank `force_rccl` communicator takes the same branch: that is how
+        // tests/test_gpu_sharding.py runs it on one GPU.)
+        if (h->n_blocks == 0) return fail(h, PF_ESTATE, "handle was created without Phyloformer weights (pf_create_bare)");
         HIPCHK(h, hipSetDevice(h->device));
         const int P0 = N * (N - 1) / 2;
         const int cb0 = chunk_batch(h, B, P0, (L_total + h->world - 1) / h->world);
-        h->reducing = true;
-        auto finish0 = [&](int code) { h->cur = h->stream; h->reducing = false; return code; };
+        ForwardScope scope(h, true);
         for (int b0 = 0; b0 < B; b0 += cb0) {
             const int nb0 = std::min(cb0, B - b0);
             Workspace w0;
             int rc0 = ensure_workspace(h, nb0, P0, 1, &w0);
-            if (rc0) return finish0(rc0);
+            if (rc0) return rc0;
             const int nh = halves_of(h, nb0);
             const int hb[2] = {nh == 2 ? (nb0 + 1) / 2 : nb0, nh == 2 ? nb0 / 2 : 0};
             hipStream_t st[2] = {h->stream, h->stream};
             float* zs[2] = {w0.srow, w0.srow + (size_t)hb[0] * P0 * SROW};      // one zero buffer per half
             float* zo[2] = {d_out + (size_t)b0 * P0, d_out + ((size_t)b0 + hb[0]) * P0};
             if (nh == 2) {
-                if ((rc0 = ensure_second_stream(h))) return finish0(rc0);
+                if ((rc0 = ensure_second_stream(h))) return rc0;
                 st[1] = h->stream2;
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
@@ -1009,20 +1022,20 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
                 for (int i = 0; i < nh; ++i) {
                     h->cur = st[i];
                     const size_t ns = (size_t)hb[i] * P0 * SROW;
-                    if (hipMemsetAsync(zs[i], 0, ns * sizeof(float), st[i]) != hipSuccess) return finish0(fail(h, PF_EHIP, "hipMemsetAsync failed"));
-                    if ((rc0 = allreduce(h, zs[i], ns))) return finish0(rc0);
+                    if (hipMemsetAsync(zs[i], 0, ns * sizeof(float), st[i]) != hipSuccess) return fail(h, PF_EHIP, "hipMemsetAsync failed");
+                    if ((rc0 = allreduce(h, zs[i], ns))) return rc0;
                 }
             for (int i = 0; i < nh; ++i) {
                 h->cur = st[i];
-                if (hipMemsetAsync(zo[i], 0, (size_t)hb[i] * P0 * sizeof(float), st[i]) != hipSuccess) return finish0(fail(h, PF_EHIP, "hipMemsetAsync failed"));
-                if ((rc0 = allreduce(h, zo[i], (size_t)hb[i] * P0))) return finish0(rc0);
+                if (hipMemsetAsync(zo[i], 0, (size_t)hb[i] * P0 * sizeof(float), st[i]) != hipSuccess) return fail(h, PF_EHIP, "hipMemsetAsync failed");
+                if ((rc0 = allreduce(h, zo[i], (size_t)hb[i] * P0))) return rc0;
             }
             if (nh == 2) {
                 HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
         }
-        return finish0(PF_OK);
+        return PF_OK;
     }
     int rc = check_dims(h, B, N, Lloc, L_total);
     if (rc) return rc;
@@ -1042,10 +1055,20 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
     return PF_OK;
 }
 
+// After a stream synchronisation: did a kernel of the forwards since the last check see a residue byte > 21?
+// (Only the device entry points can get there: pf_forward / pf_forward_sharded validate on the host first.)
+int check_bad_idx(pf_handle* h) {
+    if (!h->bad_idx_host || !*h->bad_idx_host) return PF_OK;
+    *h->bad_idx_host = 0u;
+    return fail(h, PF_EINVAL, "a residue index outside 0..21 was passed to pf_forward_device / pf_forward_sharded_device "
+                              "(treated as 21, '-'; results of the forwards since the last synchronisation are not "
+                              "those of a valid alignment)");
+}
+
 int forward_host_impl(pf_handle* h, const uint8_t* idx, int B, int N, int l_begin, int l_end,
                       int L_total, float* out) {
     const int Lloc = l_end - l_begin;
-    int rc = (Lloc == 0 && h->world > 1) ? PF_OK : check_dims(h, B, N, Lloc, L_total);
+    int rc = empty_rank_call(h, Lloc) ? PF_OK : check_dims(h, B, N, Lloc, L_total);
     if (rc) return rc;
     if (!out || (!idx && Lloc > 0)) return fail(h, PF_EINVAL, "null buffer");
     const size_t nidx = (size_t)B * N * Lloc;
@@ -1097,6 +1120,8 @@ static int open_device(int device, pf_handle** out) {
     if (device < 0 || device >= ndev) return fail(nullptr, PF_EINVAL, "device %d out of range (have %d)", device, ndev);
     pf_handle* h = new pf_handle();
     if (const char* e = getenv("PF_TWO_STREAMS")) h->two_streams = atoi(e) != 0;   // A/B runs of whole programs
+    if (getenv("PF_ROW_TILES")) h->tile_force = 0;          // read once: the tiling (and with it the layout of
+    if (getenv("PF_FLAT_TILES")) h->tile_force = 1;         // spart / outpart) cannot change between two calls
     h->device = device;
     int rc = PF_OK;
     do {
@@ -1108,6 +1133,12 @@ static int open_device(int device, pf_handle** out) {
         }
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
         h->cur = h->stream;
+        if ((e = hipHostMalloc((void**)&h->bad_idx_host, sizeof(unsigned), hipHostMallocMapped)) != hipSuccess ||
+            (e = hipHostGetDevicePointer((void**)&h->bad_idx_dev, h->bad_idx_host, 0)) != hipSuccess) {
+            rc = fail(nullptr, PF_EHIP, "hipHostMalloc (residue flag): %s", hipGetErrorString(e));
+            break;
+        }
+        *h->bad_idx_host = 0u;
         // Kernels that need more than the default 64 KB of dynamic LDS: the attribute is set here, once per
         // handle and before any launch, so that no launch path carries mutable state shared between handles
         // (the CLI drives two engines per GPU from two host threads).
@@ -1182,6 +1213,7 @@ int pf_destroy(pf_handle_t* h) {
     if (h->d_idx) hipFree(h->d_idx);
     if (h->d_out) hipFree(h->d_out);
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->bad_idx_host) hipHostFree(h->bad_idx_host);
     delete h;
     return PF_OK;
 }
@@ -1304,7 +1336,7 @@ int pf_comm_destroy(pf_handle_t* h) {
 int pf_synchronize(pf_handle_t* h) {
     if (!h) return PF_EINVAL;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PF_OK;
+    return check_bad_idx(h);
 }
 
 int pf_get_stream(pf_handle_t* h, void** s) {
@@ -1335,7 +1367,7 @@ int pf_memcpy_d2h(pf_handle_t* h, void* dst, const void* src, size_t bytes) {
     if (!h) return PF_EINVAL;
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PF_OK;
+    return check_bad_idx(h);
 }
 
 int pf_profile_reset(pf_handle_t* h) {
@@ -1388,6 +1420,14 @@ int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_
     return PF_OK;
 }
 
+int pf_device_pci(pf_handle_t* h, int32_t* domain, int32_t* bus, int32_t* device) {
+    if (!h) return PF_EINVAL;
+    if (domain) *domain = h->prop.pciDomainID;
+    if (bus) *bus = h->prop.pciBusID;
+    if (device) *device = h->prop.pciDeviceID;
+    return PF_OK;
+}
+
 // Single-GPU emulation of the site-sharded forward ("fake backend" for tests): the alignment's
 // sites are split into `nshards` ranges exactly as phyloformer_amd/dist.py::site_range does, every
 // shard gets its own workspace and runs the same kernels as a real rank, and the two collectives
@@ -1412,7 +1452,8 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
         r.B = B; r.N = N; r.P = P; r.Lloc = hi - lo; r.L_total = L;
         size_t off[WS_BUFS];
         colstats_plan(h, B, P, r.Lloc, &r.w);
-        const size_t need = workspace_bytes(B, P, r.Lloc, r.w.nparts(), off);
+        r.tp = tile_plan(h, P, r.Lloc);
+        const size_t need = workspace_bytes(h, B, P, r.Lloc, r.w.nparts(), off);
         char* ws = nullptr; uint8_t* di = nullptr; float* dout = nullptr;
         hipError_t e1 = hipMalloc((void**)&ws, need), e2 = hipMalloc((void**)&di, (size_t)B * N * r.Lloc),
                    e3 = hipMalloc((void**)&dout, (size_t)B * P * sizeof(float));

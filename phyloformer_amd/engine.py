@@ -17,7 +17,7 @@ from .weights import ModelWeights
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libphyloformer_amd.so")
-ABI_VERSION = 2            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
+ABI_VERSION = 3            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
 UNIQUE_ID_BYTES = 256      # PF_UNIQUE_ID_BYTES: two ncclUniqueIds, one per communicator / stream
 
 PF_OK, PF_EINVAL, PF_EHIP, PF_ERCCL, PF_ENOMEM, PF_ESTATE = 0, -1, -2, -3, -4, -5
@@ -66,6 +66,7 @@ SIGNATURES = {
     "pf_debug_read": (C.c_int64, [_H, C.c_char_p, C.c_void_p, C.c_int64]),
     "pf_device_info": (C.c_int, [_H, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_uint64)]),
+    "pf_device_pci": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pf_selftest": (C.c_int, [_H, C.c_void_p]),
     "pf_create_bare": (C.c_int, [C.c_int, C.POINTER(_H)]),
     "pf_mha_create": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -167,6 +168,12 @@ class Engine:
         mem = C.c_uint64()
         self._check(self._lib.pf_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)))
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    def device_pci(self) -> Tuple[int, int, int]:
+        """(domain, bus, device) of this engine's GPU - the key rocm_smi finds it by (phyloformer_amd/smi.py)."""
+        d, b, v = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.pf_device_pci(self._h, C.byref(d), C.byref(b), C.byref(v)))
+        return d.value, b.value, v.value
 
     # -- forward ----------------------------------------------------------------------------
     def forward(self, idx: np.ndarray) -> np.ndarray:

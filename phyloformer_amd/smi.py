@@ -24,6 +24,7 @@ class SmiError(RuntimeError):
 
 
 class _Frequencies(ctypes.Structure):
+    # rsmi_frequencies_t of ROCm >= 6 (this image: 7.2): the leading has_deep_sleep flag is part of the layout
     _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32),
                 ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * _MAX_FREQ)]
 
@@ -47,7 +48,11 @@ def _load():
 class Smi:
     """One device of ``librocm_smi64``.  ``device`` is the library's own index (PCI order)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, pci: "tuple[int, int, int] | None" = None):
+        """``pci`` = (domain, bus, device) of the GPU to watch - HIP ordinals follow ``HIP_VISIBLE_DEVICES``,
+        rocm_smi indexes in PCI order, so a caller that knows its engine's bus address passes it and ``device``
+        is ignored (``self.index`` / ``self.bdf`` say what was found)."""
+        self._open = False
         self._lib = _load()
         self._dev = ctypes.c_uint32(device)
         rc = self._lib.rsmi_init(ctypes.c_uint64(0))
@@ -55,12 +60,41 @@ class Smi:
             raise SmiError(f"rsmi_init failed ({rc})")
         self._open = True
         n = ctypes.c_uint32(0)
-        if self._lib.rsmi_num_monitor_devices(ctypes.byref(n)) != 0 or device >= n.value:
+        if self._lib.rsmi_num_monitor_devices(ctypes.byref(n)) != 0:
+            self.close()
+            raise SmiError("rsmi_num_monitor_devices failed")
+        if pci is not None:
+            try:
+                found = [i for i in range(n.value) if self._bdf(i)[:3] == tuple(pci)]
+            except SmiError:
+                self.close()
+                raise
+            if not found:
+                self.close()
+                raise SmiError(f"rocm_smi has no device at PCI {pci[0]:04x}:{pci[1]:02x}:{pci[2]:02x}")
+            device = found[0]
+            self._dev = ctypes.c_uint32(device)
+        if device >= n.value:
             self.close()
             raise SmiError(f"rocm_smi sees {n.value} device(s), wanted index {device}")
+        self.index = device
+        try:
+            d, b, dv, fn = self._bdf(device)
+            self.bdf = f"{d:04x}:{b:02x}:{dv:02x}.{fn:x}"
+        except SmiError:
+            self.bdf = None
+
+    def _bdf(self, index: int):
+        """(domain, bus, device, function) of rocm_smi device ``index`` (rsmi_dev_pci_id_get: domain in bits
+        63..32, bus 15..8, device 7..3, function 2..0; bits 31..28 carry a partition id on newer releases)."""
+        v = ctypes.c_uint64(0)
+        if self._lib.rsmi_dev_pci_id_get(ctypes.c_uint32(index), ctypes.byref(v)) != 0:
+            raise SmiError("rsmi_dev_pci_id_get failed")
+        x = v.value
+        return (x >> 32) & 0xffffffff, (x >> 8) & 0xff, (x >> 3) & 0x1f, x & 0x7
 
     def close(self):
-        if self._open:
+        if getattr(self, "_open", False):
             self._lib.rsmi_shut_down()
             self._open = False
 

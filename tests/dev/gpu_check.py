@@ -50,7 +50,7 @@ def main():
     for k in range(6):
         srow = e.debug_read(f"srow{k}").reshape(P, 72)
         want, _ = devmath.expected_srow(wt, k, x_in)
-        mrow = e.debug_read(f"mrow{k}").reshape(P, 5, 64)
+        mrow = e.debug_read(f"mrow{k}").reshape(P, 4, 64)   # 4 heads; the bias row is not stored
         wantm = devmath.expected_mrow(wt, k, want, L)
         ctx = e.debug_read(f"ctx{k}").reshape(L, 64)
         wantc, _ = devmath.expected_ctx(wt, k, g[f"block{k}.row"])

@@ -3,6 +3,20 @@ import os
 
 import numpy as np
 
+_GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden")
+_ANSWERS = {(20, 200): ("configs.npz", "c2_dist"), (60, 500): ("configs.npz", "c3_dist"),
+            (60, 2000): ("configs_big.npz", "c4_dist")}
+
+
+def _answer(B, N, L_total):
+    """What a correct engine returns for the committed goldens (the parity leg of bench.py feeds exactly those
+    alignments, repeated): the reference distances themselves; 0.25 for any other shape."""
+    hit = _ANSWERS.get((N, L_total))
+    if hit is None:
+        return np.full((B, N * (N - 1) // 2), 0.25, np.float32)
+    dist = np.load(os.path.join(_GOLDEN_DIR, hit[0]))[hit[1]]
+    return np.ascontiguousarray(dist[np.arange(B) % dist.shape[0]])
+
 
 class FakeEngine:
     """Engine interface used by bench.run; records what it is asked to do."""
@@ -11,6 +25,7 @@ class FakeEngine:
         self.rank, self.log, self.fail_comm_on = rank, log, fail_comm_on
         self.bufs, self.comm = {}, False
         self.calls = 0
+        self.last = None
 
     def set_option(self, k, v): self.log.append(("opt", k, v))
     def unique_id(self): return bytes(range(256))[::-1]
@@ -27,7 +42,10 @@ class FakeEngine:
     def malloc(self, n): self.bufs[len(self.bufs) + 1] = n; return len(self.bufs)
     def free(self, p): self.bufs.pop(p)
     def h2d(self, d, a): self.log.append(("h2d", a.shape))
-    def d2h(self, out, d): out[...] = 0.25
+    def d2h(self, out, d):
+        out[...] = self.last if (self.last is not None and self.last.shape == out.shape) else 0.25
+        if os.environ.get("PF_FAKE_PARITY_ERROR") == str(self.rank) and self.last is not None and self.last.shape == out.shape:
+            out[0, 0] += 1e-3           # a rank whose result is off: bench must say so and exit non-zero
     def synchronize(self): pass
     def profile_reset(self): pass
     def collective_count(self): return 14 * self.calls if self.comm else 0
@@ -43,11 +61,13 @@ class FakeEngine:
     def forward_sharded_device(self, d_idx, B, N, lo, hi, L, d_out):
         assert self.comm, "site-sharded step without a communicator"
         self.calls += 1
+        self.last = _answer(B, N, L)
         self.log.append(("sharded", B, N, lo, hi, L))
 
     def forward_device(self, d_idx, B, N, L, d_out):
         assert not self.comm, "plain forward on a handle that still carries a communicator"
         self.calls += 1
+        self.last = _answer(B, N, L)
         self.log.append(("plain", B, N, L))
 
     def forward_sharded(self, idx, lo, hi, L):
@@ -86,3 +106,23 @@ def make_dying_on_rank1(device):
 def make_hanging(device):
     import time
     time.sleep(600)
+
+
+def make_hanging_on_rung1(device):
+    """A collective that never completes on the two-stream rung (a rank spins in its first site-sharded step);
+    the one-stream rung works."""
+    eng = make_for_bench(device)
+    if os.environ.get("PF_BENCH_RUNG") == "1":
+        def stuck(*a, **k):
+            import time
+            time.sleep(600)
+        eng.forward_sharded_device = stuck
+    return eng
+
+
+def make_failing_until_rung3(device):
+    """Rung 1 hangs, on rung 2 rank 1 dies; only the alignment-sharded rung (no collective) gets through."""
+    rung = os.environ.get("PF_BENCH_RUNG")
+    if rung == "2" and os.environ.get("RANK") == "1":
+        os._exit(9)
+    return make_hanging_on_rung1(device)

@@ -25,7 +25,8 @@ def _worker(rank, world, key, tmp, fail_comm_on, q):
                              "--n-sites", "45", "--no-power"])
     log, out = [], io.StringIO()
     with TcpGroup(rank, world, key=key, directory=tmp, timeout=30) as g:
-        bench.run(args, rank, world, rank, g, lambda dev: FakeEngine(rank, log, fail_comm_on), _W(), out=out)
+        _value, ok = bench.run(args, rank, world, rank, g, lambda dev: FakeEngine(rank, log, fail_comm_on), _W(), out=out)
+        assert ok
     q.put((rank, log, out.getvalue()))
 
 
@@ -49,15 +50,26 @@ def test_bench_rank_logic_world2(fail_comm_on, tmp_path):
     if fail_comm_on is None:
         # sites 0..22 on rank 0, 23..44 on rank 1 (ceil split), global batch = batch x world
         for rank, (lo, hi) in enumerate([(0, 23), (23, 45)]):
-            steps = [e for e in res[rank][0] if e[0] == "sharded"]
+            steps = [e for e in res[rank][0] if e[0] == "sharded" and e[2] == 6]
             # warm-up + 3 timed steps on two streams, then 1 + 3 with the batch on one stream (roofline region)
             assert len(steps) == 8 and all(e == ("sharded", 4, 6, lo, hi, 45) for e in steps)
+            # parity leg: the committed 60 x 500 and 60 x 2000 reference alignments, twice each (two half-batches),
+            # through the same entry point with this rank's site range; then configs[3] timed: warm-up + 3 steps
+            gold = [e for e in res[rank][0] if e[0] == "sharded" and e[2] == 60]
+            assert gold[0] == ("sharded", 2, 60, 250 * rank, 250 * (rank + 1), 500)
+            assert gold[1] == ("sharded", 2, 60, 1000 * rank, 1000 * (rank + 1), 2000)
+            assert gold[2:] == [("sharded", 2, 60, 1000 * rank, 1000 * (rank + 1), 2000)] * 4
             opts = [e[1:] for e in res[rank][0] if e[0] == "opt" and e[1] in ("two_streams", "overlap")]
             assert opts == [("two_streams", 1), ("overlap", 1), ("two_streams", 0), ("overlap", 0),
                             ("two_streams", 1), ("overlap", 1)]
             assert ("h2d", (4, 6, hi - lo)) in res[rank][0]
         assert line["config"]["parallelism"] == "sites-sharded x2" and line["config"]["global_batch"] == 4
         assert line["config"]["rccl"]["library"].endswith("librccl.so.1")
+        c3 = line["configs"]["configs[3] 60x2000 sites-sharded x2"]
+        assert c3["sites_per_rank"] == 1000 and c3["global_batch"] == 2 and c3["alignments_per_s"] > 0 and c3["max_abs_err"] == 0.0
+        cases = line["parity"]["cases"]
+        assert set(cases) == {"configs[2] 60x500", "configs[3] 60x2000"}
+        assert all(c["entry_point"] == "pf_forward_sharded_device" and c["collectives"] == 14 and c["ok"] for c in cases.values())
         assert line["roofline"]["launches"] == 6 * 8 and line["roofline"]["traffic_source"].startswith("profiles/")
         assert line["value_one_stream"] > 0 and "one stream" in line["roofline"]["schedule"]
     else:
@@ -67,8 +79,14 @@ def test_bench_rank_logic_world2(fail_comm_on, tmp_path):
             assert ("comm_destroy",) in log
             assert not [e for e in log if e[0] == "sharded"]
             assert len([e for e in log if e == ("plain", 2, 6, 45)]) == 8
+            # the parity leg follows the fallback: whole goldens through pf_forward_device on every rank
+            assert ("plain", 2, 60, 500) in log and ("plain", 2, 60, 2000) in log
         assert line["config"]["parallelism"] == "alignments-sharded x2" and line["config"]["global_batch"] == 4
         assert "RCCL init failed" in line["config"]["note"]
+        assert all(c["entry_point"] == "pf_forward_device" and c["collectives"] == 0 for c in line["parity"]["cases"].values())
+        assert "configs[3] 60x2000 alignments-sharded x2" in line["configs"]
+    assert line["max_abs_err"] == 0.0 and line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True
+    assert line["parity"]["bound"] == 1e-4 and line["n_gpus"] == 2 and "scaling_result" not in line
 
 
 def _run_bench(argv, env_extra, timeout=120):
@@ -100,6 +118,9 @@ def test_bench_self_launch_world2(fail_comm_on, tmp_path):
         assert line["config"]["parallelism"] == "sites-sharded x2" and line["config"]["n_ranks_in_comm"] == 2
         assert line["config"]["collectives_per_step"] == 14 and line["config"]["communicators"] == 2
         assert line["config"]["reserve_cus"] == 8 and line["config"]["rccl"]["version"] == 22707
+        assert line["config"]["rung"] == {"index": 1, "name": "sites, two streams / two communicators", "abandoned": []}
+        assert line["config"]["rccl_max_nchannels"] is None          # RCCL's default unless asked for (--rccl-max-nchannels)
+        assert line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True
         for rank, (lo, hi) in enumerate([(0, 23), (23, 45)]):
             assert ["sharded", 4, 6, lo, hi, 45] in logs[rank] and ["comm_init", rank, 2] in logs[rank]
     else:
@@ -143,3 +164,67 @@ def test_power_sampler_is_evidence_only():
     assert s.summary() is None or "median_w" in s.summary()
     src = open(os.path.join(REPO, "bench.py")).read()
     assert '"rocm-smi"' not in src and "['rocm-smi" not in src, "power is read in-process, not through the rocm-smi script"
+
+
+LADDER_ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--n-seqs", "6", "--n-sites", "45", "--no-power"]
+
+
+def test_ladder_a_stalled_collective_falls_to_the_one_stream_rung(tmp_path):
+    """a collective that never completes on rung 1 (two streams / two communicators) must
+    not end the run without a number.  The launcher notices that no rank reports progress, kills exactly those
+    children, starts FRESH ones with --one-stream and relays their line, which says which rung ran and why."""
+    res = _run_bench(LADDER_ARGS + ["--stall-timeout", "4", "--rung-timeout", "40", "--launch-timeout", "100"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_hanging_on_rung1", "PF_FAKE_LOG_DIR": str(tmp_path),
+                      "TMPDIR": str(tmp_path)}, timeout=150)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip())
+    rung = line["config"]["rung"]
+    assert rung["index"] == 2 and "one stream" in rung["name"]
+    assert len(rung["abandoned"]) == 1 and rung["abandoned"][0]["rung"] == 1
+    assert "no progress" in rung["abandoned"][0]["why"] and "warm-up" not in rung["abandoned"][0]["why"]
+    assert "rank 0: communicators" in rung["abandoned"][0]["why"]          # where the ranks were stuck
+    assert line["config"]["parallelism"] == "sites-sharded x2" and line["max_abs_err_ok"] is True
+    assert "one stream" in line["roofline"]["schedule"]
+    logs = [json.load(open(tmp_path / f"rank{r}.log")) for r in range(2)]       # written by the rung that finished
+    assert all(["opt", "two_streams", 1] not in lg for lg in logs)
+
+
+def test_ladder_down_to_whole_alignments(tmp_path):
+    """Rung 1 stalls, rung 2 loses a rank: rung 3 shards whole alignments (no collective) and still delivers."""
+    res = _run_bench(LADDER_ARGS + ["--stall-timeout", "4", "--rung-timeout", "40", "--launch-timeout", "120"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_failing_until_rung3", "PF_FAKE_LOG_DIR": str(tmp_path),
+                      "TMPDIR": str(tmp_path)}, timeout=180)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip())
+    rung = line["config"]["rung"]
+    assert rung["index"] == 3 and [h["rung"] for h in rung["abandoned"]] == [1, 2]
+    assert "rank 1 exited with code 9" in rung["abandoned"][1]["why"]
+    assert line["config"]["parallelism"] == "alignments-sharded x2" and line["config"]["collectives_per_step"] == 0
+    assert line["n_gpus"] == 2 and line["max_abs_err_ok"] is True
+
+
+def test_a_failed_parity_bound_prints_the_line_and_exits_non_zero(tmp_path):
+    """The metric is alignments/s AND max-abs error: a rank whose result is off by 1e-3 makes the run exit with
+    code 3 - after the line, which carries the evidence - and no further rung is tried."""
+    res = _run_bench(LADDER_ARGS + ["--launch-timeout", "100"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_for_bench", "PF_FAKE_LOG_DIR": str(tmp_path),
+                      "PF_FAKE_PARITY_ERROR": "1", "TMPDIR": str(tmp_path)})
+    assert res.returncode == 3, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip())
+    assert line["max_abs_err_ok"] is False and line["ranks_bit_identical"] is False
+    assert abs(line["max_abs_err"] - 1e-3) < 1e-5 and line["config"]["rung"]["index"] == 1
+    assert "PARITY FAILED" in res.stderr and "rung 2" not in res.stderr
+
+
+def test_more_ranks_than_devices_is_refused_unless_allowed(tmp_path):
+    """`--gpus 2` on one device used to publish a weak-scaling number measured on a shared GPU."""
+    env = {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_for_bench", "PF_FAKE_LOG_DIR": str(tmp_path),
+           "PF_BENCH_DEVICE": "0", "TMPDIR": str(tmp_path)}
+    res = _run_bench(LADDER_ARGS + ["--launch-timeout", "100"], env)
+    assert res.returncode == 4 and res.stdout.strip() == "" and "--allow-shared-devices" in res.stderr
+    assert "rung 2" not in res.stderr                      # another schedule does not add a GPU: no further rung
+    res = _run_bench(LADDER_ARGS + ["--launch-timeout", "100", "--allow-shared-devices"], env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip())
+    assert line["n_gpus"] == 1 and line["n_ranks"] == 2 and line["ranks_per_device"] == 2 and line["scaling_result"] is False
+    assert "NOT a scaling result" in line["config"]["note"]

@@ -21,24 +21,39 @@ def _bench(argv, env_extra=None, timeout=600):
                           text=True, timeout=timeout)
 
 
+GPUS2 = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--n-seqs", "20", "--n-sites", "200",
+         "--no-cpu-baseline", "--no-power", "--launch-timeout", "300"]
+
+
 @pytest.mark.parametrize("pin", [True, False])
-def test_bench_gpus2_self_launch_on_one_gpu_falls_back_together(pin):
-    """`python3 bench.py --gpus 2`, no launcher: the parent starts two ranks, both on device 0 here
-    (PF_BENCH_DEVICE=0).  RCCL refuses two ranks on one device; the ranks agree on that, destroy their
-    communicators and shard whole alignments instead - one JSON line, exit code 0."""
-    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--n-seqs", "20", "--n-sites", "200",
-                  "--no-cpu-baseline", "--no-power", "--launch-timeout", "240"], {"PF_BENCH_DEVICE": "0"} if pin else {})
-    # (pin = False: rank 1 asks for device 1, finds one device and shares device 0 - "2 ranks on 1 device(s)")
+def test_bench_gpus2_on_one_gpu_is_refused(pin):
+    """one rank per GPU is the contract.  `python3 bench.py --gpus 2` on the 1-GPU box (both ranks
+    pinned to device 0, or rank 1 asking for a device 1 that does not exist) ends with exit code 4 on every rank,
+    no line, and no further rung of the ladder."""
+    res = _bench(GPUS2, {"PF_BENCH_DEVICE": "0"} if pin else {})
+    assert res.returncode == 4, res.stderr[-3000:]
+    assert res.stdout.strip() == "" and "--allow-shared-devices" in res.stderr and "rung 2" not in res.stderr
+
+
+def test_bench_gpus2_shared_device_falls_back_together():
+    """With --allow-shared-devices the parent starts two ranks that share device 0.  RCCL refuses two ranks on
+    one device; the ranks agree on that, destroy their communicators and shard whole alignments instead - one JSON
+    line, exit code 0, marked as NOT a scaling result (n_gpus = distinct devices), parity checked on both ranks."""
+    res = _bench(GPUS2 + ["--allow-shared-devices"])
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["workload"].startswith("configs[1]")
+    assert line["n_gpus"] == 1 and line["n_ranks"] == 2 and line["scaling_result"] is False
+    assert line["value"] > 0 and line["config"]["workload"].startswith("configs[1]")
+    assert line["config"]["rung"]["index"] == 1 and line["config"]["rung"]["abandoned"] == []
     if line["config"]["parallelism"].startswith("alignments"):
         assert "RCCL init failed" in line["config"]["note"] and line["config"]["collectives_per_step"] == 0
     else:       # a box where RCCL accepts two ranks on one device: then the real thing ran
         assert line["config"]["n_ranks_in_comm"] == 2 and line["config"]["collectives_per_step"] == 14
-    print("bench --gpus 2 on one GPU:", line["config"])
+    assert line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True and line["max_abs_err"] < 2e-5
+    assert set(line["parity"]["cases"]) == {"configs[2] 60x500", "configs[3] 60x2000"}
+    print("bench --gpus 2 on one GPU:", line["config"], line["max_abs_err"])
 
 
 def test_bench_force_dist_runs_fourteen_collectives():
@@ -51,6 +66,14 @@ def test_bench_force_dist_runs_fourteen_collectives():
     assert cfg["collectives_per_step"] == 14 and cfg["communicators"] == 2 and cfg["n_ranks_in_comm"] == 1
     assert cfg["reserve_cus"] == 8 and cfg["rccl"]["version"] > 20000 and cfg["rccl"]["library"].endswith(".so.1")
     assert line["roofline"]["launches"] == 12 and line["value"] > 0
+    # the parity leg went through the sharded entry point with real RCCL on both streams / communicators
+    cases = line["parity"]["cases"]
+    assert set(cases) == {"configs[2] 60x500", "configs[3] 60x2000"}
+    for c in cases.values():
+        assert c["entry_point"] == "pf_forward_sharded_device" and c["collectives"] == 14 and c["ok"] and c["max_abs_err"] < 2e-5
+    assert line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True
+    c3 = line["configs"]["configs[3] 60x2000 sites-sharded x1"]
+    assert c3["sites_per_rank"] == 2000 and c3["alignments_per_s"] > 0 and c3["max_abs_err"] == cases["configs[3] 60x2000"]["max_abs_err"]
 
 
 def test_two_engines_first_forward_from_two_threads(weights, golden):
@@ -104,3 +127,10 @@ def test_bench_default_line_carries_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 0.34 and r["traffic"] > 0
     assert len(d["configs"]) == 5 and all(v["alignments_per_s"] > 0 for v in d["configs"].values())
     assert d["value_pcie_inclusive"] <= d["value"] * 1.05
+    # the metric's second half: max-abs error against the reference's outputs for every BASELINE shape
+    cases = d["parity"]["cases"]
+    assert set(cases) == {"configs[1] 20x200 x3", "configs[2] 60x500", "configs[3] 60x2000", "configs[4] 200x500 gapped"}
+    assert all(c["ok"] and c["finite"] and c["max_abs_err"] < 2e-5 for c in cases.values()), cases
+    assert d["max_abs_err"] == max(c["max_abs_err"] for c in cases.values()) and d["max_abs_err_ok"] is True
+    assert d["power"] is None or d["power"]["device"]["matched_by"].startswith("pci")
+    print("parity on the bench line:", {k: c["max_abs_err"] for k, c in cases.items()})

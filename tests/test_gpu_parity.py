@@ -438,3 +438,48 @@ def test_shape_sweep_against_oracle(engines, weights):
             assert np.array_equal(np.stack([e.forward(x) for x in idx]), got), (n, l, b)
     _ERRORS["shape sweep: 40 seeded shapes, 2-15 sequences x 1-200 sites (worst)"] = {"max_abs_err": worst, "max_abs_ref": None}
     print(f"shape sweep: worst max-abs error {worst:.3e}")
+
+
+def test_device_entry_points_survive_out_of_alphabet_bytes(weights, golden):
+    """VERDICT r03 / next 4.  pf_forward refuses a residue byte > 21 on the host (ValueError; the reference raises
+    KeyError, data.py:25-26).  The device entry points take buffers the library never saw: every table lookup clamps
+    (255 reads row 21, never 60 KB past a 5.6 KB table), k_embed raises a sticky flag and the next synchronising call
+    (pf_synchronize / pf_memcpy_d2h) reports PF_EINVAL once.  Never a fault; the handle stays usable."""
+    from phyloformer_amd.engine import Engine
+    a = golden("configs.npz")["c2_idx"][:2].copy()        # 2 x (20 x 200)
+    B, N, L = a.shape
+    P = N * (N - 1) // 2
+    bad = a.copy()
+    bad[0, 3, 17] = 255
+    bad[1, :, 150:] = 22
+    as_gap = np.minimum(bad, 21)
+    with Engine(weights("pf"), 0) as e:
+        want = e.forward(as_gap)
+        with pytest.raises(ValueError, match="outside 0..21"):
+            e.forward(bad)
+        d_idx, d_out = e.malloc(bad.nbytes), e.malloc(B * P * 4)
+        out = np.empty((B, P), np.float32)
+        for opts in ({}, {"materialize_x0": 1}, {"two_streams": 0}):
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.h2d(d_idx, bad)
+            e.forward_device(d_idx, B, N, L, d_out)
+            with pytest.raises(ValueError, match="outside 0..21"):
+                e.synchronize()
+            e.d2h(out, d_out)                              # the flag was consumed: this one succeeds
+            assert np.isfinite(out).all() and np.array_equal(out, want), opts
+            for k in opts:
+                e.set_option(k, 1 if k == "two_streams" else 0)
+        e.h2d(d_idx, a)                                    # valid input afterwards: no stale flag, the usual bits
+        e.forward_device(d_idx, B, N, L, d_out)
+        e.synchronize()
+        e.d2h(out, d_out)
+        assert np.array_equal(out, e.forward(a))
+        e.set_option("embed_mfma", 1)                      # cross-check path (no k_embed): clamped, finite, no flag
+        e.h2d(d_idx, bad)
+        e.forward_device(d_idx, B, N, L, d_out)
+        e.synchronize()
+        e.d2h(out, d_out)
+        assert np.isfinite(out).all() and np.abs(out - want).max() <= 1e-4
+        e.free(d_idx)
+        e.free(d_out)

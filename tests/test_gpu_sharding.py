@@ -145,3 +145,41 @@ def test_chunk_budget_counts_both_workspaces(weights, golden):
             e.set_option("ws_limit_mb", 48)
             assert np.array_equal(e.forward(a), whole)
             e.set_option("ws_limit_mb", 24576)
+
+
+def test_empty_rank_joins_every_collective_with_zeros(weights, golden):
+    """the branch a rank without sites takes (L_total < world; `l_begin == l_end`) is the one
+    function real ranks run.  A single-rank `force_rccl` communicator takes it on one GPU: the same two halves on the
+    same two streams / communicators as its peers would issue - 14 collectives for a batch of 3 (7 with overlap off,
+    7 for a lone alignment) - and the rank's contribution, hence here the result, is all zeros.  The handle is a
+    working engine afterwards (`reducing` / `cur` are restored whatever way the call leaves)."""
+    from phyloformer_amd.engine import Engine
+    a = golden("configs.npz")["c2_idx"]                    # 3 x (20 x 200)
+    empty = np.zeros((3, 20, 0), np.uint8)
+    with Engine(weights("pf"), 0) as e:
+        ref = e.forward(a)
+        with pytest.raises(ValueError):                    # no communicator: an empty site range is just bad dims
+            e.forward_sharded(empty, 200, 200, 200)
+        e.set_option("force_rccl", 1)
+        e.comm_init(e.unique_id(), 0, 1)
+        for overlap, B, want in ((1, 3, 14), (0, 3, 7), (1, 1, 7)):
+            e.set_option("overlap", overlap)
+            e.profile_reset()
+            got = e.forward_sharded(empty[:B], 200, 200, 200)
+            assert e.collective_count() == want, (overlap, B, e.collective_count())
+            assert got.shape == (B, 190) and not got.any()
+        # device entry: the same branch, asynchronous
+        d_out = e.malloc(3 * 190 * 4)
+        e.h2d(d_out, np.ones((3, 190), np.float32))
+        e.set_option("overlap", 1)
+        e.profile_reset()
+        e.forward_sharded_device(0, 3, 20, 200, 200, 200, d_out)
+        back = np.empty((3, 190), np.float32)
+        e.d2h(back, d_out)
+        e.free(d_out)
+        assert e.collective_count() == 14 and not back.any()
+        with pytest.raises(ValueError):                    # the plain entry points never take that branch
+            e.forward(empty)
+        assert np.array_equal(e.forward_sharded(a, 0, 200, 200), ref)       # full range again: a normal forward
+        e.comm_destroy()
+        assert np.array_equal(e.forward(a), ref)
