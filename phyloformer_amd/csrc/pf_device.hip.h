@@ -553,10 +553,12 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     lds_frag_t w1p = lw + FRAG_W1 + lane;   // per-lane bases: all later offsets are immediates
     lds_frag_t w2p = lw + FRAG_W2 + lane;
     lds_frag_t wop = lw + FRAG_WO + lane;
-    lds_frag_t wvp = lw + FRAG_WV + lane;
     lds_frag_t qkp = lw + FRAG_QK + h * 8 + (t & 7);
     lds_f32_t lch = lc + 4 * h;
-    PF_OPAQUE(wop); PF_OPAQUE(wvp); PF_OPAQUE(qkp); PF_OPAQUE(lch);
+    PF_OPAQUE(wop); PF_OPAQUE(qkp); PF_OPAQUE(lch);
+    // Wv' hi sits 16 KB behind Wo in the image: the same per-lane base, the distance in the 16-bit offset field of
+    // ds_read_b128 (one base register less to keep alive across the tile loop)
+    lds_frag_t wvp = wop + (FRAG_WV - FRAG_WO);
 
     {
         // Tiles are dealt in short RUNS of consecutive tiles, round-robin over the waves: at any moment the
@@ -597,7 +599,12 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             pqr = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
             pqc = *reinterpret_cast<const f32x4*>(a.qcol + tk * 4);
             if (MODE != MODE_FIRST) {
-                const f32x4* cp = reinterpret_cast<const f32x4*>(a.ctx + ((size_t)pb * a.Lloc + ll) * 64 + 4 * h);
+                // (h through an opaque copy: hipcc otherwise hoists the per-lane 64-bit base a.ctx + 4 h out of the tile
+                // loop, where it does not find a register pair for it - round 3's build kept it in scratch and
+                // reloaded it once per tile; recomputing costs one 64-bit add)
+                int hq = h;
+                asm volatile("" : "+v"(hq));
+                const f32x4* cp = reinterpret_cast<const f32x4*>(a.ctx + ((size_t)pb * a.Lloc + ll) * 64 + 4 * hq);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) pctx[g] = cp[2 * g];
             }
@@ -900,7 +907,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             task = ntask;
         }
     }
-    if (a.prof && lane == 0) {
+    // (the lane number from the hardware, not from a register that would have to live across the tile loop)
+    if (a.prof && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, tacc[k]);
     }

@@ -58,7 +58,7 @@ def test_bench_gpus2_shared_device_falls_back_together():
 
 def test_bench_force_dist_runs_fourteen_collectives():
     """The N > 1 code path of bench.py (rendezvous, two RCCL communicators, two streams) with one rank."""
-    res = _bench(["--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-power", "--no-configs",
+    res = _bench(["--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-power",
                   "--batch", "4", "--n-seqs", "20", "--n-sites", "200"])
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
