@@ -11,7 +11,9 @@ alignment ``OUTDIR/<stem>.phy`` receives the PHYLIP distance matrix
 (``%.10f``) and, with ``-t``, ``OUTDIR/<stem>.nj.nwk`` a neighbour-joining tree.
 
 Additive flags (not in the reference): ``--device`` / ``--devices 0,1,...`` (one
-process per GPU, files sharded), ``--batch`` (same-shape alignments per launch;
+process per GPU; ``--shard files`` - the default - deals the files to the GPUs, ``--shard sites``
+spreads every alignment over them: each rank holds a block of sites, RCCL all-reduces inside
+``pf_forward_sharded``, rank 0 writes the outputs), ``--batch`` (same-shape alignments per launch;
 default: fill a token budget per shape), ``--io-threads``, ``--gpu-streams``, ``--python-io``,
 ``--bench`` (print a JSON timing line).  Scheduling lives in
 ``phyloformer_amd/scheduler.py``: files are bucketed by shape, parsed ahead of the
@@ -45,6 +47,11 @@ def build_parser():
     parser.add_argument("--devices", default=None,
                         help="comma-separated HIP device ordinals: shard the files over these GPUs, "
                              "one process per GPU (alignment-level data parallelism, no collective)")
+    parser.add_argument("--shard", choices=["files", "sites"], default="files",
+                        help="with --devices: 'files' (default) gives every GPU its share of the files, no collective; "
+                             "'sites' spreads every alignment over the GPUs (each holds L / n sites of every pair, the "
+                             "row-attention statistics and the final site sums are all-reduced over RCCL): for "
+                             "alignments too long or too few to fill the GPUs one file each")
     parser.add_argument("--batch", type=int, default=0,
                         help="same-shape alignments per launch; 0 (default) = fill a token budget per shape, "
                              "1 = one alignment per launch as in the reference")
@@ -79,12 +86,20 @@ def main(argv=None):
                     k = child_argv.index(flag)
                     del child_argv[k:k + 2]
             child_argv = [a for a in child_argv if not a.startswith("--devices=") and not a.startswith("--device=")]
-            rc, reports = scheduler.run_multi_device(os.path.abspath(__file__), child_argv, devices)
+            for flag in ("--shard",):
+                while flag in child_argv:
+                    k = child_argv.index(flag)
+                    del child_argv[k:k + 2]
+            child_argv = [a for a in child_argv if not a.startswith("--shard=")]
+            rc, reports = scheduler.run_multi_device(os.path.abspath(__file__), child_argv, devices, shard=args.shard)
             if args.bench:
                 wall = time.perf_counter() - t0
-                n = sum(r["alignments"] for r in reports)
-                print(json.dumps({"alignments": n, "devices": devices, "wall_s_incl_startup": round(wall, 4),
-                                  "alignments_per_s": round(sum(r["alignments_per_s"] or 0 for r in reports), 3),
+                sites = args.shard == "sites" and all(r.get("site_sharded_over") for r in reports)
+                # site-sharded ranks all work on every alignment: the job's count and rate are rank 0's
+                n = (reports[0]["alignments"] if reports else 0) if sites else sum(r["alignments"] for r in reports)
+                rate = (reports[0]["alignments_per_s"] or 0) if (sites and reports) else sum(r["alignments_per_s"] or 0 for r in reports)
+                print(json.dumps({"alignments": n, "devices": devices, "shard": args.shard if sites or args.shard == "files" else "files (fallback)",
+                                  "wall_s_incl_startup": round(wall, 4), "alignments_per_s": round(rate, 3),
                                   "workers": reports}), file=sys.stderr)
             return rc
         args.device = devices[0]
@@ -96,17 +111,21 @@ def main(argv=None):
     except Exception:  # pragma: no cover
         tqdm = None
 
-    t0 = time.perf_counter()
-    model = Phyloformer.from_checkpoint(args.weights, device=args.device)
-    model.eval()
-    load_s = time.perf_counter() - t0
-
     paths = glob(f"{in_dir}/*")
     rank, world = 0, 1
     if args.worker:
         rank, world = (int(v) for v in args.worker.split("/"))
     elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])   # launched by torchrun
+
+    if args.shard == "sites" and (world > 1 or os.environ.get("PF_CLI_FORCE_RCCL")):
+        return run_site_sharded(args, paths, rank, world, out_dir, tqdm)
+
+    t0 = time.perf_counter()
+    model = Phyloformer.from_checkpoint(args.weights, device=args.device)
+    model.eval()
+    load_s = time.perf_counter() - t0
+
     if world > 1:
         for p in paths:
             if not scheduler.has_fasta_ext(p):
@@ -116,8 +135,7 @@ def main(argv=None):
     bar = tqdm(total=len(paths)) if (tqdm is not None and world == 1) else None
     engines = [model.engine]
     if args.batch != 1:
-        from phyloformer_amd.engine import Engine
-        engines += [Engine(model.weights, device=args.device) for _ in range(max(1, args.gpu_streams) - 1)]
+        engines += [scheduler.cli_engine(model.weights, args.device) for _ in range(max(1, args.gpu_streams) - 1)]
     if len(engines) > 1:
         # several engines already keep several streams busy; each splitting its batches over two more only adds
         # contention (tools/cli_bench.py, same box: 505 against 498 alignments/s)
@@ -139,6 +157,72 @@ def main(argv=None):
         e.close()
     model.close()
     return 0
+
+
+def run_site_sharded(args, paths, rank, world, out_dir, tqdm):
+    """One rank of ``--devices ... --shard sites`` (started by scheduler.run_multi_device, which set the rendezvous
+    environment).  The ranks first agree that every one of them has its RCCL communicators; if not, all of them
+    destroy theirs and fall back to ``--shard files`` (each its share of the files, no collective) - a run that
+    still writes every output.  ``PF_CLI_FORCE_RCCL=1`` makes a single process take this path with a real
+    single-rank communicator (the GPU test of a 1-GPU box)."""
+    from phyloformer_amd import dist as pfdist
+    from phyloformer_amd import scheduler
+    from phyloformer_amd.weights import load_weights
+
+    t0 = time.perf_counter()
+    weights = load_weights(args.weights)
+    engine = scheduler.cli_engine(weights, args.device)
+    load_s = time.perf_counter() - t0
+    group = None
+    try:
+        if world > 1:
+            from phyloformer_amd.rendezvous import TcpGroup
+            group = TcpGroup(rank, world)
+            ok, why = 1, ""
+            try:
+                pfdist.init_engine_comm(engine, group)
+            except Exception as exc:  # noqa: BLE001 - every rank learns about it below
+                ok, why = 0, f"rank {rank}: {type(exc).__name__}: {exc}"
+            seen = group.allgather([ok, why])
+            if not all(o for o, _ in seen):
+                engine.comm_destroy()
+                if rank == 0:
+                    print("infer_alns: site-sharding unavailable (" + "; ".join(w for o, w in seen if not o) +
+                          "); sharding the files over the GPUs instead", file=sys.stderr)
+                for p in paths:
+                    if not scheduler.has_fasta_ext(p):
+                        raise ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{p}")
+                runner = scheduler.DirectoryRunner([engine], out_dir, trees=args.trees, batch=args.batch,
+                                                   io_threads=args.io_threads, native_io=not args.python_io)
+                stats = runner.run(scheduler.slice_paths(paths, rank, world))
+                group.barrier()
+                if args.bench:
+                    rep = scheduler.summarize(stats, load_s)
+                    rep["device"] = args.device
+                    print(json.dumps(rep), file=sys.stderr)
+                return 0
+        else:
+            engine.set_option("force_rccl", 1)
+            engine.comm_init(engine.unique_id(), 0, 1)
+        bar = tqdm(total=len(paths)) if (tqdm is not None and rank == 0 and not args.worker) else None
+        runner = scheduler.SiteShardedRunner(engine, group, rank, world, out_dir, trees=args.trees, batch=args.batch,
+                                             io_threads=args.io_threads, native_io=not args.python_io,
+                                             progress=bar.update if bar is not None else None)
+        try:
+            stats = runner.run(paths)
+        finally:
+            if bar is not None:
+                bar.close()
+        if args.bench:
+            rep = scheduler.summarize(stats, load_s)
+            rep.update({"device": args.device, "site_sharded_over": world, "rank": rank,
+                        "collectives": engine.collective_count() if hasattr(engine, "collective_count") else None})
+            print(json.dumps(rep), file=sys.stderr)
+        return 0
+    finally:
+        if group is not None:
+            group.close()
+        engine.close()
 
 
 if __name__ == "__main__":

@@ -15,7 +15,12 @@ by a wide margin.  This module keeps the GPU fed:
 * two engines on two host threads (``--gpu-streams``) keep the GPU busy across the
   host-side gaps of the synchronous ``pf_forward``;
 * ``run_multi_device`` shards the *files* over several GPUs, one process per
-  GPU, no collective (alignment-level data parallelism, SURVEY.md §8e way 1).
+  GPU, no collective (alignment-level data parallelism, SURVEY.md §8e way 1);
+* ``--shard sites`` (``SiteShardedRunner``) spreads every alignment over the GPUs instead
+  (SURVEY.md §8e way 2): each rank parses the file, keeps its block of sites and calls
+  ``pf_forward_sharded`` - n_blocks + 1 RCCL all-reduces per launch - and rank 0 writes the
+  outputs.  The ranks meet through ``rendezvous.TcpGroup`` and walk the files in ONE
+  deterministic order (collectives must be issued in the same order everywhere).
 
 Every alignment is computed independently inside a launch and no launch parameter
 that affects the order of a sum depends on the batch size: an alignment's distances
@@ -207,6 +212,111 @@ class DirectoryRunner:
         return self.stats
 
 
+class SiteShardedRunner(DirectoryRunner):
+    """``--shard sites``: every alignment is spread over the ``world`` ranks of one node.
+
+    Rank ``r`` holds the sites ``dist.site_range(L, world, r)`` of every pair; the row-attention statistics
+    (/root/reference/phyloformer/attention.py:183-190 reduced over sites, model.py:91) and the final site sums
+    (model.py:185) are all-reduced inside ``pf_forward_sharded``, so every rank receives the full distance
+    vector and rank 0 alone writes ``<stem>.phy`` / ``<stem>.nj.nwk`` (output contract: infer_alns.py:105-123).
+
+    Collectives must be issued in the same order on every rank: all ranks sort the paths the same way, parse
+    every file themselves (the parse is cheap beside a sharded forward of a long alignment), bucket by shape in
+    that order on ONE host thread and flush the partial buckets in sorted shape order.  Before each launch the
+    ranks compare (shape, batch, checksum of the file names) through the rendezvous: a directory that differs
+    between ranks is an error on all of them, not a hang."""
+
+    def __init__(self, engine, group, rank: int, world: int, out_dir: str, **kw):
+        super().__init__([engine], out_dir, **kw)
+        self.group, self.rank, self.world = group, rank, world
+        self.stats["site_sharded_over"] = world
+
+    def _launch_sharded(self, shape, group_items, writers, pending):
+        import zlib
+        from .dist import site_range
+        engine = self.engines[0]
+        N, L = shape
+        lo, hi = site_range(L, self.world, self.rank)
+        if self.group is not None:
+            tag = [N, L, len(group_items), zlib.crc32("\n".join(os.path.basename(g[0]) for g in group_items).encode())]
+            seen = self.group.allgather(tag)
+            if any(list(t) != tag for t in seen):
+                raise RuntimeError(f"site-sharded ranks disagree on the next launch: {seen} (do all ranks see the same files?)")
+        local = np.ascontiguousarray(np.stack([g[1] for g in group_items])[:, :, lo:hi])
+        t0 = time.perf_counter()
+        preds = engine.forward_sharded(local, lo, hi, L)
+        self.stats["forward_s"] += time.perf_counter() - t0
+        self.stats["launches"] += 1
+        self.stats["alignments"] += len(group_items)
+        key = f"{N}x{L}"
+        self.stats["shapes"][key] = self.stats["shapes"].get(key, 0) + len(group_items)
+        if self.rank == 0:
+            for (path, _idx, ids), pred in zip(group_items, preds):
+                pending.append(writers.submit(self._write, path, pred, ids))
+            while len(pending) > 8 * self.io_threads + len(group_items):
+                pending.popleft().result()
+        if self.progress is not None:
+            self.progress(len(group_items))
+
+    def run(self, paths: Sequence[str]) -> dict:
+        for p in paths:
+            if not has_fasta_ext(p):
+                raise ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{p}")
+        paths = sorted(paths)
+        t_start = time.perf_counter()
+        buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
+        pending: deque = deque()
+        lookahead = max(16, 2 * (self.batch or 16))
+        with ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-load") as loaders, \
+                ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-write") as writers:
+            inflight: "deque[Tuple[str, Future]]" = deque()
+            it = iter(paths)
+            exhausted = False
+            while True:
+                while not exhausted and len(inflight) < lookahead:
+                    try:
+                        p = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        break
+                    inflight.append((p, loaders.submit(self._load, p)))
+                if not inflight:
+                    break
+                path, fut = inflight.popleft()
+                t0 = time.perf_counter()
+                idx, ids = fut.result()
+                self.stats["load_wait_s"] += time.perf_counter() - t0
+                shape = (int(idx.shape[0]), int(idx.shape[1]))
+                bucket = buckets.setdefault(shape, [])
+                bucket.append((path, idx, ids))
+                if len(bucket) >= (self.batch or auto_batch(shape[0], shape[1], token_budget=TOKEN_BUDGET * self.world)):
+                    self._launch_sharded(shape, bucket, writers, pending)
+                    buckets[shape] = []
+            for shape in sorted(buckets):
+                if buckets[shape]:
+                    self._launch_sharded(shape, buckets[shape], writers, pending)
+            t0 = time.perf_counter()
+            while pending:
+                pending.popleft().result()
+            self.stats["write_wait_s"] += time.perf_counter() - t0
+        if self.group is not None:
+            self.group.barrier()
+        self.stats["wall_s"] = time.perf_counter() - t_start
+        return self.stats
+
+
+def cli_engine(weights, device: int):
+    """The engine the CLI drives.  ``PF_CLI_ENGINE_FACTORY=module:function`` swaps in a stand-in with the Engine
+    interface (``function(weights, device)``): the CPU tests of the multi-rank plumbing, which have no GPU."""
+    hook = os.environ.get("PF_CLI_ENGINE_FACTORY")
+    if hook:
+        import importlib
+        mod_name, fn = hook.split(":")
+        return getattr(importlib.import_module(mod_name), fn)(weights, device)
+    from .engine import Engine
+    return Engine(weights, device=device)
+
+
 def summarize(stats: dict, load_s: float = 0.0) -> dict:
     n, wall = stats["alignments"], stats.get("wall_s", 0.0)
     return {"alignments": n, "launches": stats["launches"], "shapes": stats["shapes"],
@@ -219,13 +329,31 @@ def summarize(stats: dict, load_s: float = 0.0) -> dict:
             if stats["forward_s"] > 0 else None}
 
 
-def run_multi_device(script: str, argv: List[str], devices: Sequence[int]) -> Tuple[int, List[dict]]:
-    """One child process per GPU, each on its own share of the files (``--worker r/W``).
+def run_multi_device(script: str, argv: List[str], devices: Sequence[int], shard: str = "files") -> Tuple[int, List[dict]]:
+    """One child process per GPU (``--worker r/W``): each on its own share of the files, or - ``shard="sites"`` -
+    all of them on every file, each with its block of sites; the ranks then meet through the rendezvous the
+    environment set here names (127.0.0.1, a free port, a run id).
     Children are started before any of them touches a GPU; the parent never does."""
     procs = []
+    env = dict(os.environ)
+    if shard == "sites":
+        import socket
+        import uuid
+        s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver only supports dmabuf IPC, which RCCL's intra-node
+        # transports need; exported on the boxes already, pinned here for the children - DESIGN.md section 6)
+        env.update({"WORLD_SIZE": str(len(devices)), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "PF_RUN_ID": uuid.uuid4().hex,
+                    "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     for r, d in enumerate(devices):
         cmd = [sys.executable, script, *argv, "--device", str(d), "--worker", f"{r}/{len(devices)}", "--bench"]
-        procs.append(subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True))
+        if shard == "sites":
+            cmd += ["--shard", "sites"]
+        procs.append(subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)) if shard == "sites" else None))
     rc, reports = 0, []
     for p in procs:
         _out, err = p.communicate()

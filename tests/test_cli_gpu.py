@@ -114,3 +114,37 @@ def test_cli_file_sharding_over_worker_processes(repo, tmp_path):
     for name in sorted(os.listdir(out)):
         ids, dm = _read_phy(out / name)
         assert np.abs(dm[np.triu_indices(len(ids), 1)] - gold["pf/" + name[:-4]]).max() <= 1e-4
+
+
+def test_cli_site_sharded_with_a_real_communicator(repo, tmp_path):
+    """`--shard sites` on the GPU.  One box has one GPU, so the rank is alone
+    (PF_CLI_FORCE_RCCL=1: a real single-rank RCCL communicator pair) - but it runs the path the ranks of
+    `--devices 0,..,7 --shard sites` run: SiteShardedRunner, pf_forward_sharded, 14 collectives per batched launch
+    on two streams.  Byte-identical files to the plain run; the two-rank plumbing itself is tests/test_scheduler.py."""
+    ind = os.path.join(repo, "data/testdata/msas")
+    a, b = tmp_path / "sites", tmp_path / "plain"
+    r = _run(repo, [os.path.join(repo, "models/pf.ckpt"), ind, "-o", str(a), "--shard", "sites", "--bench", "-t"],
+             env=dict(os.environ, PF_CLI_FORCE_RCCL="1"))
+    assert r.returncode == 0, r.stderr
+    rep = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+    assert rep["alignments"] == 20 and rep["launches"] == 4 and rep["site_sharded_over"] == 1
+    assert rep["collectives"] == 4 * 14                     # four shape buckets of five alignments: two halves each
+    r = _run(repo, [os.path.join(repo, "models/pf.ckpt"), ind, "-o", str(b), "-t"])
+    assert r.returncode == 0, r.stderr
+    names = sorted(os.listdir(b))
+    assert names == sorted(os.listdir(a)) and len(names) == 40
+    for n in names:
+        assert (a / n).read_bytes() == (b / n).read_bytes(), n
+    # two ranks on ONE GPU: RCCL refuses, the ranks agree and fall back to sharding the files - everything is written
+    c = tmp_path / "two"
+    r = _run(repo, [os.path.join(repo, "models/pf.ckpt"), ind, "-o", str(c), "--devices", "0,0", "--shard", "sites", "--bench"])
+    assert r.returncode == 0, r.stderr
+    rep = json.loads([l for l in r.stderr.splitlines() if l.startswith("{") and '"workers"' in l][-1])
+    if rep["shard"] == "sites":          # a box where RCCL takes two ranks on one device: the real thing ran
+        assert rep["alignments"] == 20 and all(w["site_sharded_over"] == 2 for w in rep["workers"])
+    else:
+        assert "site-sharding unavailable" in r.stderr and rep["alignments"] == 20
+    for n in (x for x in names if x.endswith(".phy")):
+        ids, dm = _read_phy(c / n)
+        _ids, dm_b = _read_phy(b / n)
+        assert np.abs(dm - dm_b).max() <= 2e-5

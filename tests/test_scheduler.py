@@ -1,9 +1,13 @@
 """CPU tests of the CLI scheduler (phyloformer_amd/scheduler.py) with a stand-in engine:
 shape bucketing, batch sizes, output files, error propagation, file sharding across workers."""
+import json
 import os
+import sys
 
 import numpy as np
 import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from phyloformer_amd import fasta, scheduler
 from phyloformer_amd.phylip import vec_to_phylip
@@ -120,3 +124,72 @@ def test_two_gpu_worker_threads_and_worker_errors(tmp_path):
             raise RuntimeError("device lost")
     with pytest.raises(RuntimeError, match="device lost"):
         scheduler.DirectoryRunner([Boom(), Boom()], str(out), batch=2).run(paths)
+
+
+# ---- --shard sites: the CLI's multi-rank plumbing at world 2, with real numerics (oracle engine) ----------------
+def _cli(argv, env_extra, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), REPO, env.get("PYTHONPATH", "")])
+    return subprocess.run([sys.executable, os.path.join(REPO, "infer_alns.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.fixture(scope="module")
+def small_dir(tmp_path_factory):
+    from phyloformer_amd.msa_sim import simulate_batch
+    d = tmp_path_factory.mktemp("alns")
+    for k, a in enumerate(simulate_batch(3, 6, 41, seed=11)):
+        _write_fasta(d / f"a{k}.fa", a)
+    for k, a in enumerate(simulate_batch(2, 5, 33, seed=12, gaps=True)):
+        _write_fasta(d / f"b{k}.fasta", a)
+    _write_fasta(d / "c0.fa", simulate_batch(1, 4, 1, seed=13)[0])      # one site: rank 1 of 2 holds none of it
+    return d
+
+
+def test_cli_site_sharded_world2_writes_what_one_process_writes(small_dir, tmp_path):
+    """`infer_alns.py --devices 0,1 --shard sites` - the north star's split behind the north
+    star's surface.  Two ranks (fresh children of the CLI, TcpGroup rendezvous) each parse every file, keep their
+    block of sites, exchange the row statistics of every block and the final site sums; rank 0 alone writes.  With
+    the oracle engine the numerics are real: the .phy and .nwk files are byte-identical to a one-process run that
+    evaluates the same two-shard sums (output contract: /root/reference/infer_alns.py:105-123)."""
+    env = {"PF_CLI_ENGINE_FACTORY": "helpers.oracle_engine:make", "TMPDIR": str(tmp_path)}
+    ckpt = os.path.join(REPO, "models", "pf_base.ckpt")
+    r = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "sites"), "-t", "--devices", "0,1", "--shard", "sites", "--batch", "2",
+              "--bench"], env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{") and '"workers"' in ln][-1])
+    assert rep["shard"] == "sites" and rep["alignments"] == 6 and len(rep["workers"]) == 2
+    assert all(w["site_sharded_over"] == 2 and w["alignments"] == 6 and w["launches"] == 4 for w in rep["workers"])
+    assert all(w["collectives"] == 7 * 6 for w in rep["workers"])            # n_blocks + 1 per alignment (oracle engine)
+    one = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "one"), "-t", "--batch", "1"], dict(env, PF_ORACLE_SHARDS="2"))
+    assert one.returncode == 0, one.stderr[-3000:]
+    names = sorted(os.listdir(tmp_path / "one"))
+    assert names == sorted(os.listdir(tmp_path / "sites")) and len(names) == 12
+    for n in names:
+        assert (tmp_path / "sites" / n).read_bytes() == (tmp_path / "one" / n).read_bytes(), n
+    # and the sharded sums are the plain forward's to fp32 noise
+    plain = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "plain")], env)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    for n in names:
+        if n.endswith(".phy"):
+            a = np.array([[float(v) for v in ln.split(" ")[1:]] for ln in (tmp_path / "sites" / n).read_text().splitlines()[1:]])
+            b = np.array([[float(v) for v in ln.split(" ")[1:]] for ln in (tmp_path / "plain" / n).read_text().splitlines()[1:]])
+            assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+def test_cli_site_sharded_falls_back_to_files_when_a_communicator_fails(small_dir, tmp_path):
+    """A rank whose RCCL communicator does not come up is named; ALL ranks drop theirs and shard the files instead:
+    every output is still written, by whichever rank got the file."""
+    env = {"PF_CLI_ENGINE_FACTORY": "helpers.oracle_engine:make", "PF_FAKE_FAIL_COMM_ON": "1", "TMPDIR": str(tmp_path)}
+    ckpt = os.path.join(REPO, "models", "pf_base.ckpt")
+    r = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "fb"), "--devices", "0,1", "--shard", "sites", "--bench"], env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "site-sharding unavailable (" in r.stderr and "rank 1: RuntimeError" in r.stderr and "sharding the files" in r.stderr
+    rep = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{") and '"workers"' in ln][-1])
+    assert rep["shard"] == "files (fallback)" and rep["alignments"] == 6 and sorted(w["alignments"] for w in rep["workers"]) == [3, 3]
+    plain = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "plain")], {k: v for k, v in env.items() if k != "PF_FAKE_FAIL_COMM_ON"})
+    assert plain.returncode == 0
+    for n in sorted(os.listdir(tmp_path / "plain")):
+        assert (tmp_path / "fb" / n).read_bytes() == (tmp_path / "plain" / n).read_bytes(), n
