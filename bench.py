@@ -845,6 +845,7 @@ def main(argv=None):
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args, argv)          # before anything touches the GPU
+    beat("process up")          # (the launcher's stall watchdog counts from the last mark of ANY rank)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -866,7 +867,9 @@ def main(argv=None):
 
     from phyloformer_amd.rendezvous import TcpGroup
     w, make_engine, make_engine_for = engine_factories(args.ckpt)
+    beat("weights loaded")
     group = TcpGroup(rank, world) if (world > 1 or args.force_dist) else None
+    beat("rendezvous")
     ok = True
     try:
         _value, ok = run(args, rank, world, local_rank, group, make_engine, w, out=line_out, make_engine_for=make_engine_for)

@@ -554,7 +554,7 @@ constexpr int WS_BUFS = 10;
 int colstats_groups(int /*B*/, int P, int Lloc) {
     // A wave walks its group's pairs one after the other (0.7 us each): the walk length is the kernel's
     // latency for a lone alignment, but every extra group costs a 33 KB partial per 32-site chunk (HBM write
-    // + read) and a pipeline fill.  Measured at 60 x 500 (tools/colstats_compare.py), 8 / 16 / 32 groups:
+    // + read) and a pipeline fill.  Measured at 60 x 500 (tools/colstats_runs_compare.py), 8 / 16 / 32 groups:
     // 0.91 / 0.98 / 0.99 ms per launch at batch 16, 0.165 / 0.099 / 0.067 ms at batch 1.  The headline is the
     // batched rate: >= 128 blocks per alignment, <= 640 and >= 32 pairs per group.
     const int chunks = (Lloc + 31) / 32;

@@ -3,7 +3,7 @@ import json, os, subprocess, sys
 for name in sys.argv[1:]:
     p = os.path.join("phyloformer_amd", name)
     env = dict(os.environ, PHYLOFORMER_AMD_LIB=os.path.abspath(p))
-    out = subprocess.run([sys.executable, "bench.py", "--steps", os.environ.get("PF_AB_STEPS", "8"), "--warmup", "2", "--no-cpu-baseline", "--no-power", "--no-configs"], env=env,
+    out = subprocess.run([sys.executable, "bench.py", "--steps", os.environ.get("PF_AB_STEPS", "8"), "--warmup", "2", "--no-cpu-baseline", "--no-power", "--no-configs", "--no-parity"], env=env,
                          capture_output=True, text=True).stdout
     try:
         d = json.loads(out.strip().splitlines()[-1])

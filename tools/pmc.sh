@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BATCH=${PMC_BATCH:-16}
 # --one-stream: a launch covers the whole batch (the per-dispatch means below are per full-batch launch)
-ARGS="--steps 1 --warmup 1 --batch $BATCH --no-cpu-baseline --no-configs --no-profile --one-stream $*"
+ARGS="--steps 1 --warmup 1 --batch $BATCH --no-cpu-baseline --no-configs --no-parity --no-profile --one-stream $*"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" \
