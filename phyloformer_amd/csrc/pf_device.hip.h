@@ -527,14 +527,27 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
     lds_f32_t lc = (lds_f32_t)(smem + FRAG_END * 16);
 
     {
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        const uint4* src = reinterpret_cast<const uint4*>(a.wimg);
-        // MODE_FIRST only needs the row-statistics operands; the last block only the FFN/out_proj
-        const int lo = (MODE == MODE_FIRST) ? FRAG_WV : 0;
-        const int hi = (MODE == MODE_LAST) ? FRAG_WV : FRAG_END;
-        for (int i = lo + threadIdx.x; i < hi; i += MAIN_THREADS) dst[i] = src[i];
-        float* dc = reinterpret_cast<float*>(smem + FRAG_END * 16);
-        for (int i = threadIdx.x; i < CONST_LEN; i += MAIN_THREADS) dc[i] = a.consts[i];
+        // The LDS image (157 KB per workgroup, L2-resident after the first one) is requested in ONE go:
+        // global_load_lds_dwordx4 moves 16 bytes per lane straight into LDS (destination = wave-uniform base +
+        // lane * 16: the image is linear, so wave w of step k lands fragments 512 k + 64 w ..), no staging
+        // registers, all ~20 requests of a wave in flight before the single wait.  Until round 4 this was a
+        // load - wait - ds_write loop, one L2 round trip per step: ~10 us per launch - nothing in a 4 ms launch,
+        // a third of k_main's 28 us when a lone 20 x 200 alignment gives every wave one tile.
+        // MODE_FIRST only needs the row-statistics operands; the last block only the FFN / out_proj
+        constexpr int lo = (MODE == MODE_FIRST) ? FRAG_WV : 0;
+        constexpr int hi = (MODE == MODE_LAST) ? FRAG_WV : FRAG_END;
+        static_assert(lo % 64 == 0 && hi % 64 == 0 && FRAG_END % 64 == 0, "the image is copied in whole waves");
+        const bf16x8* src = a.wimg;
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const float cv = a.consts[min((int)threadIdx.x, CONST_LEN - 1)];
+#pragma unroll
+        for (int k = 0; k < (hi - lo + MAIN_THREADS - 1) / MAIN_THREADS; ++k) {
+            const int f0 = lo + k * MAIN_THREADS + wv * 64;            // wave-uniform first fragment of this request
+            if (f0 < hi) __builtin_amdgcn_global_load_lds(src + f0 + ln, smem + (size_t)f0 * 16, 16, 0, 0);
+        }
+        static_assert(CONST_LEN <= MAIN_THREADS, "one constant per thread");
+        if (threadIdx.x < CONST_LEN) reinterpret_cast<float*>(smem + FRAG_END * 16)[threadIdx.x] = cv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
@@ -944,12 +957,26 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
     float* tab = esm;
     float* emb = esm + PAIRTAB_ROWS * PAIRTAB_W;
     {
+        // the 139 KB pair table in one go (see k_main): 17 direct-to-LDS requests per wave in flight at once, the
+        // last 8 vectors and the 5.6 KB embedding table through registers
+        constexpr int NV = PAIRTAB_ROWS * PAIRTAB_W / 4, FULL = NV / EMBED_THREADS;     // 8,712 vectors: 17 whole steps
         const f32x4* src = reinterpret_cast<const f32x4*>(a.ptab);
         f32x4* dst = reinterpret_cast<f32x4*>(tab);
-        for (int i = threadIdx.x; i < PAIRTAB_ROWS * PAIRTAB_W / 4; i += EMBED_THREADS) dst[i] = src[i];
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < FULL; ++k) {
+            const int v0 = k * EMBED_THREADS + wv * 64;
+            __builtin_amdgcn_global_load_lds(src + v0 + ln, tab + (size_t)v0 * 4, 16, 0, 0);
+        }
+        const int it = FULL * EMBED_THREADS + threadIdx.x;
+        const f32x4 tail = src[min(it, NV - 1)];
         const f32x4* s2 = reinterpret_cast<const f32x4*>(a.table);
         f32x4* d2 = reinterpret_cast<f32x4*>(emb);
-        for (int i = threadIdx.x; i < 22 * 64 / 4; i += EMBED_THREADS) d2[i] = s2[i];
+        static_assert(22 * 64 / 4 <= EMBED_THREADS, "one embedding vector per thread");
+        const f32x4 ev = s2[min((int)threadIdx.x, 22 * 64 / 4 - 1)];
+        if (it < NV) dst[it] = tail;
+        if (threadIdx.x < 22 * 64 / 4) d2[threadIdx.x] = ev;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1069,18 +1096,21 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
         const float* sp = a.srow + (size_t)first * SROW;
         // lanes 0..63 take S_kv[c], lanes 0..7 also S_q | S_k; four partials in flight per lane
         const int c2 = 64 + (c & 7);
+        // eight partials in flight per lane and round, the tail masked (uniform conditions; x + 0 leaves every bit
+        // of x): a row of <= 8 tiles - every shape up to 256 sites - costs ONE round trip, where a 4-wide loop with
+        // a scalar remainder took four for the 7 tiles of a 200-site row
         float acc = 0.f, acc2 = 0.f;
-        int i = 0;
-        for (; i + 4 <= nparts; i += 4) {
+        for (int i = 0; i < nparts; i += 8) {
             const float* q0 = sp + i * SROW;
-            const float v0 = q0[c], v1 = q0[SROW + c], v2 = q0[2 * SROW + c], v3 = q0[3 * SROW + c];
-            const float w0 = q0[c2], w1 = q0[SROW + c2], w2 = q0[2 * SROW + c2], w3 = q0[3 * SROW + c2];
-            acc = (((acc + v0) + v1) + v2) + v3;
-            acc2 = (((acc2 + w0) + w1) + w2) + w3;
-        }
-        for (; i < nparts; ++i) {
-            acc += sp[i * SROW + c];
-            acc2 += sp[i * SROW + c2];
+            float v[8], w8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool on = i + q < nparts;
+                v[q] = on ? q0[q * SROW + c] : 0.f;
+                w8[q] = on ? q0[q * SROW + c2] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { acc += v[q]; acc2 += w8[q]; }
         }
         st[sub][c] = acc;
         if (c < 8) st[sub][64 + c] = acc2;
@@ -1135,7 +1165,13 @@ __global__ void k_rowsum(const float* spart, float* srow, int npairs, int nparts
     part_range(flat, pr, nparts_, P, Lloc, slots_aln, &first, &nparts);
     const float* sp = spart + (size_t)first * SROW + c;
     float acc = 0.f;
-    for (int k = 0; k < nparts; ++k) acc += sp[(size_t)k * SROW];
+    for (int k = 0; k < nparts; k += 8) {          // eight loads in flight, summed in index order (see k_rowfin)
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = k + q < nparts ? sp[(size_t)(k + q) * SROW] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
     srow[i] = acc;
 }
 
@@ -1149,7 +1185,13 @@ __global__ void k_outsum(const float* outpart, float* out, int npairs, int npart
     part_range(flat, pr, nparts_, P, Lloc, slots_aln, &first, &nparts);
     const float* sp = outpart + first;
     float acc = 0.f;
-    for (int k = 0; k < nparts; ++k) acc += sp[k];
+    for (int k = 0; k < nparts; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = k + q < nparts ? sp[k + q] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
     out[pr] = acc * inv_L_total;
 }
 
@@ -1198,8 +1240,14 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     constexpr int PIJ_CAP = 640;
     __shared__ int16_t pij[EMBED ? 2 * PIJ_CAP : 2];
     if (EMBED) {
-        for (int i = threadIdx.x; i < 22 * 64 / 4; i += 256)
-            reinterpret_cast<f32x4*>(emb)[i] = reinterpret_cast<const f32x4*>(a.table)[i];
+        // both requests in flight before the first store (a load - wait - store loop costs one L2 round trip per step)
+        constexpr int NV = 22 * 64 / 4;
+        const f32x4* tsrc = reinterpret_cast<const f32x4*>(a.table);
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+        static_assert(NV <= 2 * 256, "two vectors per thread cover the table");
+        const f32x4 v0 = tsrc[min(i0, NV - 1)], v1 = tsrc[min(i1, NV - 1)];
+        if (i0 < NV) reinterpret_cast<f32x4*>(emb)[i0] = v0;
+        if (i1 < NV) reinterpret_cast<f32x4*>(emb)[i1] = v1;
         // visible to all waves after the __syncthreads() that follows the first staging request
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1447,26 +1495,36 @@ __global__ void __launch_bounds__(COLFIN_THREADS) k_colfin(ColFinArgs a) {
         // partials are summed in run, then group order (fixed association); up to eight loads in flight
         float acc = 0.f;
         if (a.fine) {
+            // four groups a round, four runs of each in flight: up to sixteen loads per thread before the first add
+            // (a lone alignment's forward is a chain of such latencies); the sums associate as before - a group's
+            // runs in run order from zero, then the groups in group order
+            constexpr int GU = 4;
             const float* pp = a.part + ((size_t)b * a.G * a.S * a.Lloc + l) * CPART + i;
-            for (int g = 0; g < a.G; g += 2) {
-                const bool two = g + 1 < a.G;
-                const int n0 = (min(a.npairs, (g + 1) * per) - g * per + a.sub - 1) / a.sub;
-                const int n1 = two ? (min(a.npairs, (g + 2) * per) - (g + 1) * per + a.sub - 1) / a.sub : 0;
-                const float* p0 = pp + (size_t)g * a.S * gs;
-                const float* p1 = p0 + (size_t)a.S * gs;
-                float t0 = 0.f, t1 = 0.f;
-                for (int s = 0; s < max(n0, n1); s += 4) {
-                    float v[4], u[4];
+            for (int g = 0; g < a.G; g += GU) {
+                int n[GU], nmax = 0;
+                const float* pg[GU];
+                float t[GU];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {      // (uniform conditions; x + 0 leaves every bit of x)
-                        v[q] = s + q < n0 ? p0[(size_t)(s + q) * gs] : 0.f;
-                        u[q] = s + q < n1 ? p1[(size_t)(s + q) * gs] : 0.f;
-                    }
-                    t0 = (((t0 + v[0]) + v[1]) + v[2]) + v[3];
-                    t1 = (((t1 + u[0]) + u[1]) + u[2]) + u[3];
+                for (int u = 0; u < GU; ++u) {
+                    const int gg = g + u;
+                    n[u] = gg < a.G ? (min(a.npairs, (gg + 1) * per) - gg * per + a.sub - 1) / a.sub : 0;
+                    nmax = max(nmax, n[u]);
+                    pg[u] = pp + (size_t)gg * a.S * gs;
+                    t[u] = 0.f;
                 }
-                acc += t0;
-                if (two) acc += t1;
+                for (int s = 0; s < nmax; s += 4) {
+                    float v[GU][4];
+#pragma unroll
+                    for (int u = 0; u < GU; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)      // (uniform conditions; x + 0 leaves every bit of x)
+                            v[u][q] = s + q < n[u] ? pg[u][(size_t)(s + q) * gs] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) t[u] = (((t[u] + v[u][0]) + v[u][1]) + v[u][2]) + v[u][3];
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+                    if (g + u < a.G) acc += t[u];
             }
         } else {
             const float* pp = a.part + ((size_t)b * a.G * a.Lloc + l) * CPART + i;
