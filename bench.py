@@ -824,6 +824,108 @@ def self_launch(args, argv):
     return rc
 
 
+def supervise(args, argv, rank, world):
+    """`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: the processes the launcher started
+    do not become ranks - a stalled collective would then hang until someone else's timeout, with no number.  Each
+    becomes the SUPERVISOR of one rank instead: it touches neither HIP nor the engine, starts the real rank as a fresh
+    child of this script and watches it; the supervisors meet in a rendezvous of their own and walk the same ladder
+    as `self_launch` in lockstep (every 0.25 s they exchange their child's exit code and the age of its last progress
+    mark; the verdict is a function of the exchanged values, so all of them reach it together): a dead or stalled rank
+    anywhere makes every supervisor kill its child and start a fresh one for the next rung, under a new rendezvous
+    key.  Supervisor 0 relays its child's JSON line.  Exit code: the rung's, as in `self_launch`."""
+    from phyloformer_amd.rendezvous import TcpGroup, default_key
+    base_run = os.environ.get("PF_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    sup = TcpGroup(rank, world, key=default_key() + "_supervisors", timeout=max(30.0, args.rung_timeout))
+    t_launch = time.monotonic()
+    history, rc, text = [], 1, ""
+    rungs = ladder(args)
+    first = len(RUNGS) - len(rungs) + 1
+    try:
+        for index, (name, extra) in enumerate(rungs, start=first):
+            left = args.launch_timeout - (time.monotonic() - t_launch)
+            if any(sup.allgather(index > first and left < 15)):
+                if rank == 0:
+                    print("bench: no time left for another rung", file=sys.stderr)
+                break
+            progress = tempfile.mkdtemp(prefix="pf_bench_progress_")
+            env = dict(os.environ, PF_RUN_ID=f"{base_run}_rung{index}", PF_BENCH_RUNG=str(index), PF_BENCH_RUNG_NAME=name,
+                       PF_BENCH_RUNG_HISTORY=json.dumps(history), PF_BENCH_PROGRESS=progress,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv) + extra, env=env,
+                                     stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL)
+            out0 = []
+            reader = None
+            if rank == 0:
+                reader = threading.Thread(target=lambda: out0.append(child.stdout.read()), daemon=True)
+                reader.start()
+            t0, last, size = time.monotonic(), time.monotonic(), 0
+            mark = os.path.join(progress, f"rank{rank}")
+            rc, why = 0, ""
+            while True:
+                try:
+                    sz = os.path.getsize(mark)
+                except OSError:
+                    sz = 0
+                now = time.monotonic()
+                if sz != size:
+                    size, last = sz, now
+                stage = "-"
+                try:
+                    with open(mark) as fh:
+                        stage = (fh.read().strip().splitlines() or ["- -"])[-1].split(" ", 1)[-1]
+                except OSError:
+                    pass
+                seen = sup.allgather([child.poll(), round(now - last, 2), round(now - t0, 2),
+                                      round(now - t_launch, 2), stage])
+                codes = [c for c, *_ in seen]
+                where = "; ".join(f"rank {r}: {st}" for r, (*_x, st) in enumerate(seen))
+                if any(c not in (None, 0) for c in codes):
+                    bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                    rc = bad[0][1] if all(c == bad[0][1] for _, c in bad) and bad[0][1] in (EXIT_PARITY, EXIT_DEVICES) else 1
+                    why = ", ".join(f"rank {r} exited with code {c}" for r, c in bad)
+                    if rc == 1:
+                        time.sleep(0.5)
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if seen[0][2] > args.rung_timeout or seen[0][3] > args.launch_timeout:
+                    rc, why = EXIT_WATCHDOG, f"watchdog: ranks still running after {seen[0][2]:.0f} s ({where})"
+                    break
+                if min(age for _c, age, *_ in seen) > args.stall_timeout:
+                    rc, why = EXIT_WATCHDOG, f"watchdog: no progress from any rank for {args.stall_timeout:.0f} s ({where})"
+                    break
+                time.sleep(0.25)
+            if child.poll() is None:            # exactly the process started above
+                child.terminate()
+                try:
+                    child.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    child.kill()
+                    child.wait()
+            if reader is not None:
+                reader.join(timeout=5)
+            shutil.rmtree(progress, ignore_errors=True)
+            text = (out0[0] if out0 else b"").decode(errors="replace")
+            if rc and rank == 0:
+                print(f"bench: rung {index} ({name}): {why}; all {world} ranks stopped", file=sys.stderr)
+            if rc == 0 and not any(sup.allgather(rank == 0 and not text.strip())):
+                break
+            if rc == 0:
+                rc, why = 1, "rank 0 printed nothing"
+            if rc in (EXIT_PARITY, EXIT_DEVICES):
+                break
+            history.append({"rung": index, "name": name, "why": why})
+            text = ""
+    finally:
+        sup.close()
+    if rank == 0 and text:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    if rc and history and rc not in (EXIT_PARITY, EXIT_DEVICES):
+        rc = EXIT_WATCHDOG if all("watchdog" in h["why"] for h in history) else 1
+    return rc
+
+
 def engine_factories(ckpt):
     """(weights, make_engine(device), make_engine_for(ckpt, device)).  PF_BENCH_ENGINE_FACTORY=module:function
     swaps in a stand-in for the CPU test of the self-launch path: ``function(device)`` returns an object with the
@@ -845,6 +947,10 @@ def main(argv=None):
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args, argv)          # before anything touches the GPU
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1 and "PF_BENCH_RUNG" not in os.environ \
+            and not os.environ.get("PF_BENCH_NO_SUPERVISOR"):
+        # started by an external launcher (torch.distributed.run): supervise a fresh child per rung (see supervise)
+        return supervise(args, argv, int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"]))
     beat("process up")          # (the launcher's stall watchdog counts from the last mark of ANY rank)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

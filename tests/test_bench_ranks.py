@@ -228,3 +228,41 @@ def test_more_ranks_than_devices_is_refused_unless_allowed(tmp_path):
     line = json.loads(res.stdout.strip())
     assert line["n_gpus"] == 1 and line["n_ranks"] == 2 and line["ranks_per_device"] == 2 and line["scaling_result"] is False
     assert "NOT a scaling result" in line["config"]["note"]
+
+
+def _torchrun(argv, env_extra, timeout=240):
+    """bench.py the way the task statement says the driver starts an N > 1 run."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), REPO, env.get("PYTHONPATH", "")])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py")] + argv
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("factory", ["make_for_bench", "make_hanging_on_rung1"])
+def test_under_torchrun_every_process_supervises_a_fresh_rank(factory, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` (the task statement's N > 1 form): the
+    processes torchrun starts become supervisors, the ranks are their fresh children, and the ladder works as in the
+    self-launched form - a collective that never completes on rung 1 ends as a rung-2 line, not as a hang."""
+    res = _torchrun(LADDER_ARGS + ["--stall-timeout", "4", "--rung-timeout", "40", "--launch-timeout", "100"],
+                    {"PF_BENCH_ENGINE_FACTORY": f"helpers.fake_engine:{factory}", "PF_FAKE_LOG_DIR": str(tmp_path),
+                     "TMPDIR": str(tmp_path)})
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "sites-sharded x2" and line["max_abs_err_ok"] is True
+    if factory == "make_for_bench":
+        assert line["config"]["rung"] == {"index": 1, "name": "sites, two streams / two communicators", "abandoned": []}
+        assert line["config"]["collectives_per_step"] == 14
+    else:
+        rung = line["config"]["rung"]
+        assert rung["index"] == 2 and rung["abandoned"][0]["rung"] == 1 and "no progress" in rung["abandoned"][0]["why"]
+        assert "rung 1" in res.stderr

@@ -134,3 +134,24 @@ def test_bench_default_line_carries_the_contract():
     assert d["max_abs_err"] == max(c["max_abs_err"] for c in cases.values()) and d["max_abs_err_ok"] is True
     assert d["power"] is None or d["power"]["device"]["matched_by"].startswith("pci")
     print("parity on the bench line:", {k: c["max_abs_err"] for k, c in cases.items()})
+
+
+def test_bench_under_torchrun_two_ranks_share_the_gpu():
+    """The task statement's N > 1 form - `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` - on
+    the 1-GPU box: torchrun's processes become supervisors (no HIP), their fresh children are the ranks; RCCL refuses
+    two ranks on one device, the ranks agree and shard whole alignments; supervisor 0 relays the one JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py")] + GPUS2 + ["--allow-shared-devices"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_ranks"] == 2 and line["n_gpus"] == 1 and line["scaling_result"] is False and line["value"] > 0
+    assert line["config"]["rung"]["index"] == 1 and line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True
