@@ -1268,7 +1268,7 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     // the row out_proj bias is the same for every pair: eight registers instead of two of the ten 16-byte LDS
     // reads per lane and pair (the LDS pipe is what this kernel is closest to)
     const f32x4 br0 = *reinterpret_cast<const f32x4*>(a.brow + 8 * cl), br1 = *reinterpret_cast<const f32x4*>(a.brow + 8 * cl + 4);
-    const bool up2 = (cl & 4) != 0, up1 = (cl & 2) != 0, up0 = (cl & 1) != 0;
+    const bool up1 = (cl & 2) != 0, up0 = (cl & 1) != 0;
     int bid = blockIdx.x;
     int run = 0;
     if (a.fine) { run = bid % a.S; bid /= a.S; }
@@ -1410,11 +1410,9 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
                 for (int i = 1; i < 8; ++i) acc = fmaf(w[o][i], d[u][i], acc);
                 pv[o] = acc;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float send = up2 ? pv[i] : pv[i + 4], keep = up2 ? pv[i + 4] : pv[i];
-                pv[i] = keep + dpp_f<0x141>(send);
-            }
+            // lane-bit-2 step without selects: two masked DPP adds per value pair (bank_mask picks the 4-lane groups
+            // each is meant for; same operands and pairing as keep + dpp(send), see treduce_step4_masked)
+            treduce_step4_masked(pv);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float send = up1 ? pv[i] : pv[i + 2], keep = up1 ? pv[i + 2] : pv[i];

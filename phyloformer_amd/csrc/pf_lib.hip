@@ -1072,8 +1072,16 @@ int forward_host_impl(pf_handle* h, const uint8_t* idx, int B, int N, int l_begi
     if (rc) return rc;
     if (!out || (!idx && Lloc > 0)) return fail(h, PF_EINVAL, "null buffer");
     const size_t nidx = (size_t)B * N * Lloc;
-    for (size_t i = 0; i < nidx; ++i)
-        if (idx[i] >= NA) return fail(h, PF_EINVAL, "residue index %d at offset %zu is outside 0..21", (int)idx[i], i);
+    {
+        // one branch-free pass the compiler vectorises (an early-exit byte loop cost 0.2 ms per batch of 16 x 60 x 500:
+        // most of what separated the host-buffer rate from the device-resident one); the offender is looked for only
+        // if there is one
+        unsigned bad = 0;
+        for (size_t i = 0; i < nidx; ++i) bad |= (unsigned)(idx[i] >= NA);
+        if (bad)
+            for (size_t i = 0; i < nidx; ++i)
+                if (idx[i] >= NA) return fail(h, PF_EINVAL, "residue index %d at offset %zu is outside 0..21", (int)idx[i], i);
+    }
     HIPCHK(h, hipSetDevice(h->device));
     const int P = N * (N - 1) / 2;
     if (nidx > h->d_idx_bytes || !h->d_idx) {
@@ -1133,7 +1141,7 @@ static int open_device(int device, pf_handle** out) {
         }
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, PF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
         h->cur = h->stream;
-        if ((e = hipHostMalloc((void**)&h->bad_idx_host, sizeof(unsigned), hipHostMallocMapped)) != hipSuccess ||
+        if ((e = hipHostMalloc((void**)&h->bad_idx_host, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
             (e = hipHostGetDevicePointer((void**)&h->bad_idx_dev, h->bad_idx_host, 0)) != hipSuccess) {
             rc = fail(nullptr, PF_EHIP, "hipHostMalloc (residue flag): %s", hipGetErrorString(e));
             break;
