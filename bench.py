@@ -119,9 +119,9 @@ def parse_args(argv=None):
                     help="let several ranks share a GPU when there are more ranks than devices (the line is then "
                          "marked as not a scaling result); without it such a run exits with code 4")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (max_abs_err vs the committed reference outputs)")
-    ap.add_argument("--launch-timeout", type=float, default=345.0,
+    ap.add_argument("--launch-timeout", type=float, default=400.0,
                     help="self-launch (--gpus N > 1 without a launcher): seconds for all rungs of the fallback ladder together")
-    ap.add_argument("--rung-timeout", type=float, default=120.0, help="self-launch: seconds one rung of the ladder may take")
+    ap.add_argument("--rung-timeout", type=float, default=150.0, help="self-launch: seconds one rung of the ladder may take")
     ap.add_argument("--stall-timeout", type=float, default=75.0,
                     help="self-launch: a rung whose ranks report no progress for this long is abandoned")
     return ap.parse_args(argv)
