@@ -4,11 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
 
 N = 1 runs in this process.  N > 1 *without* a launcher environment (``WORLD_SIZE`` unset) makes this process
-a launcher: before any HIP call and without importing the engine it picks a free ``MASTER_PORT``, starts N
-fresh children of itself with ``RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / PF_RUN_ID`` set,
-relays rank 0's JSON line and exits non-zero if a child fails or the watchdog (``--launch-timeout``) fires.
-Under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` the environment is already
-there and every process is a rank.
+a launcher: before any HIP call and without importing the engine it picks a free ``MASTER_PORT`` and starts N
+fresh children of itself with ``RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / PF_RUN_ID`` set.
+Those - like the N processes of ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``, the
+other way to start an N > 1 run - do not become ranks: each *supervises* one rank, a fresh child of its own
+(``supervise``), so that a stalled collective ends as a line from the next rung of the ladder below, not as a hang.
 
 A *step* is one pass of the hot path (``pf_forward_device`` / ``pf_forward_sharded_device``) over one batch of
 synthetic alignments whose residue indices are already resident in HBM.  Default workload: BASELINE.json
@@ -22,8 +22,8 @@ forward, issued per half-batch on two streams / two communicators: 14 per step).
 grows -> "weak".  ``--shard alignments`` shards whole alignments instead (no collective).  The ranks meet
 through ``phyloformer_amd.rendezvous.TcpGroup`` (standard library, no torch import in a GPU rank).
 
-Fallback ladder (self-launch only): the launcher runs rung 1 = sites on two streams / two communicators; if a
-rank dies, stops making progress (``--stall-timeout``) or the rung exceeds ``--rung-timeout``, those children are
+Fallback ladder: the supervisors run rung 1 = sites on two streams / two communicators; if a
+rank dies, no rank makes progress (``--stall-timeout``) or the rung exceeds ``--rung-timeout``, those ranks are
 killed and FRESH ones are started for rung 2 = ``--one-stream`` (serial collectives on one stream), then rung 3 =
 ``--shard alignments`` (no collective).  A rank is never re-exec'ed.  The line records ``config.rung`` and why
 earlier rungs were abandoned.  Exit codes: 0 ok; 3 = the parity bound failed (the line is still printed, no
@@ -706,133 +706,66 @@ def rung_info():
         return None
 
 
-def launch_rung(args, argv, world, index, name, history, deadline):
-    """One rung: N fresh children of this script, one per GPU.  Returns (rc, why, rank 0's stdout).  rc 0 only if
-    every rank exited 0 before the rung's limits: ``--rung-timeout`` seconds in total, ``--stall-timeout`` seconds
-    without a progress mark from any rank (bench.beat), the launch's overall ``deadline``."""
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` without a launcher: this process touches neither HIP nor the engine.  It starts N
+    fresh children of this script with the environment an external launcher would give them (``RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT / PF_RUN_ID``) - and those, like the processes of
+    ``torch.distributed.run``, become the *supervisors* of the ranks (``supervise``): ONE implementation of the
+    fallback ladder serves both forms.  Supervisor 0 inherits this process's stdout and prints the JSON line; every
+    child's stderr is inherited.  Returns the supervisors' common exit code (they agree by construction); if they
+    are still there ``--launch-timeout`` + 45 s after the start, their process groups are killed and the code is 124."""
+    world = args.gpus
     env = dict(os.environ)
-    progress = tempfile.mkdtemp(prefix="pf_bench_progress_")
     # HSA_ENABLE_IPC_MODE_LEGACY=0: the GPU pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's
     # intra-node transport setup fails with "hipIpcGetMemHandle: invalid argument" (task statement, Environment).
     # It is already exported on the boxes; the launcher pins it for its children in case a wrapper dropped it.
     env.update({"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
-                "PF_RUN_ID": uuid.uuid4().hex, "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                "PF_BENCH_RUNG": str(index), "PF_BENCH_RUNG_NAME": name, "PF_BENCH_RUNG_HISTORY": json.dumps(history),
-                "PF_BENCH_PROGRESS": progress})
+                "PF_RUN_ID": uuid.uuid4().hex, "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    for k in ("PF_BENCH_RUNG", "PF_BENCH_RUNG_NAME", "PF_BENCH_RUNG_HISTORY", "PF_BENCH_PROGRESS"):
+        env.pop(k, None)
     procs = []
     for r in range(world):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    t_start = time.monotonic()
-    rung_deadline = min(deadline, t_start + args.rung_timeout)
-    rc, why = 0, ""
-    out0 = []
-    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    marks, last_progress = {}, t_start
-
-    def progress_seen():
-        nonlocal last_progress
-        for r in range(world):
-            try:
-                sz = os.path.getsize(os.path.join(progress, f"rank{r}"))
-            except OSError:
-                sz = 0
-            if marks.get(r) != sz:
-                marks[r] = sz
-                last_progress = time.monotonic()
-
-    def where():
-        out = []
-        for r in range(world):
-            try:
-                with open(os.path.join(progress, f"rank{r}")) as fh:
-                    out.append(f"rank {r}: " + (fh.read().strip().splitlines() or ["-"])[-1].split(" ", 1)[-1])
-            except OSError:
-                out.append(f"rank {r}: no progress mark")
-        return "; ".join(out)
-
-    while True:
-        codes = [p.poll() for p in procs]
-        if any(c not in (None, 0) for c in codes):
-            # a rank that dies usually takes its peers down with it (they lose the rendezvous connection):
-            # give them a moment, then name every rank that failed, not just the first one seen
-            time.sleep(0.5)
-            bad = [(r, p.poll()) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            rc = bad[0][1] if all(c == bad[0][1] for _, c in bad) and bad[0][1] in (EXIT_PARITY, EXIT_DEVICES) else 1
-            why = ", ".join(f"rank {r} exited with code {c}" for r, c in bad)
-            break
-        if all(c == 0 for c in codes):
-            break
-        now = time.monotonic()
-        progress_seen()
-        if now > rung_deadline:
-            rc, why = EXIT_WATCHDOG, f"watchdog: ranks still running after {now - t_start:.0f} s ({where()})"
-            break
-        if now - last_progress > args.stall_timeout:
-            rc, why = EXIT_WATCHDOG, f"watchdog: no progress from any rank for {args.stall_timeout:.0f} s ({where()})"
-            break
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), start_new_session=True,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + args.launch_timeout + 45.0
+    while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
         time.sleep(0.05)
-    if rc:
-        for p in procs:                 # exactly the processes started above, by PID
-            if p.poll() is None:
-                p.terminate()
-        t_kill = time.monotonic() + 5
-        for p in procs:
+    late = [p for p in procs if p.poll() is None]
+    for p in late:                      # exactly the process groups started above (a supervisor and its rank)
+        try:
+            os.killpg(p.pid, 15)
+        except OSError:
+            pass
+    for p in late:
+        try:
+            p.wait(timeout=5)
+        except subprocess.TimeoutExpired:
             try:
-                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
-        print(f"bench: rung {index} ({name}): {why}; all {world} ranks stopped", file=sys.stderr)
-    reader.join(timeout=5)
-    shutil.rmtree(progress, ignore_errors=True)
-    return rc, why, (out0[0] if out0 else b"").decode(errors="replace")
-
-
-def self_launch(args, argv):
-    """Parent of the ranks.  Touches neither HIP nor the engine: it only starts fresh children of this script, one
-    per GPU, and waits.  Rank 0's stdout (the JSON line) is relayed; every child's stderr is inherited.  A rung
-    that loses a rank or stalls is abandoned - its children are killed by PID - and the next rung of the ladder
-    starts FRESH children (a hung collective cannot be recovered inside its processes, and a rank that has
-    touched the GPU must never exec).  Returns 0 if some rung produced the line with every rank exiting 0."""
-    world = args.gpus
-    deadline = time.monotonic() + args.launch_timeout
-    history, rc, text = [], 1, ""
-    rungs = ladder(args)
-    first = len(RUNGS) - len(rungs) + 1             # rungs are numbered 1..3 whatever subset runs
-    for index, (name, extra) in enumerate(rungs, start=first):
-        if index > first and time.monotonic() + 15 > deadline:
-            print("bench: no time left for another rung", file=sys.stderr)
-            break
-        rc, why, text = launch_rung(args, list(argv) + extra, world, index, name, history, deadline)
-        if rc == 0 and text.strip():
-            break
-        if rc == 0:
-            rc, why = 1, "rank 0 printed nothing"
-            print(f"bench: rung {index}: {why}", file=sys.stderr)
-        if rc in (EXIT_PARITY, EXIT_DEVICES):
-            break           # a result that fails its bound, or a box without the GPUs: another schedule changes neither
-        history.append({"rung": index, "name": name, "why": why})
-        text = ""
-    if text:
-        sys.stdout.write(text)
-        sys.stdout.flush()
-    if rc and history and rc not in (EXIT_PARITY, EXIT_DEVICES):
-        rc = EXIT_WATCHDOG if all("watchdog" in h["why"] for h in history) else 1
-    return rc
+                os.killpg(p.pid, 9)
+            except OSError:
+                pass
+            p.wait()
+    if late:
+        print(f"bench: watchdog: {len(late)} supervisor(s) still running {args.launch_timeout + 45:.0f} s after the start; "
+              "killed", file=sys.stderr)
+        return EXIT_WATCHDOG
+    codes = [p.returncode for p in procs]
+    if len(set(codes)) > 1:
+        print(f"bench: supervisors disagree on the exit code: {codes}", file=sys.stderr)
+    return next((c for c in codes if c), 0)
 
 
 def supervise(args, argv, rank, world):
-    """`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: the processes the launcher started
-    do not become ranks - a stalled collective would then hang until someone else's timeout, with no number.  Each
-    becomes the SUPERVISOR of one rank instead: it touches neither HIP nor the engine, starts the real rank as a fresh
-    child of this script and watches it; the supervisors meet in a rendezvous of their own and walk the same ladder
-    as `self_launch` in lockstep (every 0.25 s they exchange their child's exit code and the age of its last progress
-    mark; the verdict is a function of the exchanged values, so all of them reach it together): a dead or stalled rank
-    anywhere makes every supervisor kill its child and start a fresh one for the next rung, under a new rendezvous
-    key.  Supervisor 0 relays its child's JSON line.  Exit code: the rung's, as in `self_launch`."""
+    """The processes a launcher started (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or
+    `self_launch`) do not become ranks - a stalled collective would then hang until someone else's timeout, with no
+    number.  Each becomes the SUPERVISOR of one rank instead: it touches neither HIP nor the engine, starts the real
+    rank as a fresh child of this script and watches it; the supervisors meet in a rendezvous of their own and walk
+    the fallback ladder in lockstep (every 0.25 s they exchange their child's exit code and the age of its last
+    progress mark; the verdict is a function of the exchanged values, so all of them reach it together): a dead or
+    stalled rank anywhere makes every supervisor kill its child and start a fresh one for the next rung, under a new
+    rendezvous key.  Supervisor 0 relays its child's JSON line.  Exit code: 0, or 3 / 4 from the ranks (parity bound,
+    too few GPUs: final), 124 if every rung was abandoned by a watchdog, else 1."""
     from phyloformer_amd.rendezvous import TcpGroup, default_key
     base_run = os.environ.get("PF_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID", "none")
     sup = TcpGroup(rank, world, key=default_key() + "_supervisors", timeout=max(30.0, args.rung_timeout))
