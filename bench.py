@@ -866,6 +866,8 @@ def engine_factories(ckpt):
     hook = os.environ.get("PF_BENCH_ENGINE_FACTORY")
     if hook:
         import importlib
+        print(f"bench: PF_BENCH_ENGINE_FACTORY={hook} REPLACES the GPU engine (test hook; the line's config.device names "
+              "the stand-in)", file=sys.stderr)
         mod_name, fn = hook.split(":")
         mod = importlib.import_module(mod_name)
         return mod.bench_weights(), getattr(mod, fn), None

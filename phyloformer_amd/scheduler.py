@@ -311,6 +311,9 @@ def cli_engine(weights, device: int):
     hook = os.environ.get("PF_CLI_ENGINE_FACTORY")
     if hook:
         import importlib
+        # a test hook, never set by the product: say so on every use, so that a run through a stand-in cannot pass
+        # for a GPU run (there is no CPU fallback: without the hook a missing library or GPU is an error)
+        print(f"infer_alns: PF_CLI_ENGINE_FACTORY={hook} REPLACES the GPU engine (test hook)", file=sys.stderr)
         mod_name, fn = hook.split(":")
         return getattr(importlib.import_module(mod_name), fn)(weights, device)
     from .engine import Engine

@@ -155,3 +155,16 @@ def test_bench_under_torchrun_two_ranks_share_the_gpu():
     line = json.loads(lines[0])
     assert line["n_ranks"] == 2 and line["n_gpus"] == 1 and line["scaling_result"] is False and line["value"] > 0
     assert line["config"]["rung"]["index"] == 1 and line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True
+
+
+def test_bench_force_dist_one_stream_is_rung_two():
+    """Rung 2 of the ladder (`--one-stream`: one stream, one communicator in use, serial collectives) with real
+    single-rank RCCL: 7 collectives per step and per parity case, the same distances."""
+    res = _bench(["--force-dist", "--one-stream", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-power",
+                  "--no-configs", "--batch", "4", "--n-seqs", "20", "--n-sites", "200"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["config"]["collectives_per_step"] == 7 and "one stream" in line["roofline"]["schedule"]
+    cases = line["parity"]["cases"]
+    assert all(c["collectives"] == 7 and c["ok"] and c["max_abs_err"] < 2e-5 for c in cases.values()), cases
+    assert line["configs"] is None and line["max_abs_err_ok"] is True
