@@ -1,3 +1,4 @@
+"""Headline step at several batch sizes, two passes (watch the order: a box warms up within a pass): python tools/batch_sweep.py"""
 import json, os, subprocess, sys
 for rep in range(2):
     for b in (8, 12, 16, 20, 24, 32):
