@@ -1206,7 +1206,7 @@ struct ColStatsArgs {
     const float* bqk;    // [8]
     const float* brow;   // [64] row out_proj bias of this block (row 4 of every pair's mrow: read once, not per pair)
     int B, P, Lloc, G, nchunks;
-    // Fixed two-level association of the sum over pairs: every group is cut into runs of `sub` pairs (a multiple
+    // Fixed two-level association of the sum over pairs: every group is cut into runs of `sub` pairs (8, or a multiple
     // of 16; S = runs per group); a run is summed pair by pair from zero, a group is the in-order sum of its
     // runs, the total (k_colfin) the in-order sum of the groups.  fine = 0: one block walks a whole group and
     // folds run after run in registers (part[b][g][l]); fine = 1: one block per run (part[b][g][s][l]) and
@@ -1441,6 +1441,8 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
                 z[3][i] = fmaf(k3, d[u][i], z[3][i]);
             }
         }
+        // runs of 8 pairs (short groups): the run boundary in the middle of a staged tile (fine = 0 only; wave-uniform)
+        if (a.sub == 8 && !a.fine && p + 2 - pt == 8 && p + 2 < pe) fold();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetches) have landed
       __syncthreads();

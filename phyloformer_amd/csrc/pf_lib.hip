@@ -574,7 +574,10 @@ void colstats_plan(const pf_handle* h, int B, int P, int Lloc, Workspace* w) {
     const int per = (P + w->G - 1) / w->G;
     // (measured at 60 x 500: folding every 32 pairs costs the batched walk 1 %, every 64 nothing; a lone
     // alignment's launch takes 68 us either way, and k_colfin 18 / 11 us)
-    w->sub = per >= 128 ? 64 : per >= 64 ? 32 : 16;
+    // (runs of 8 for groups of 16 .. 47 pairs - round 4: a lone small alignment walks a run in 4 iterations instead
+    // of 8, 20 x 200 batch 1 +6 %; groups of >= 48 pairs - every 60-sequence shape, sharded or not - keep 16, and a
+    // group shorter than two runs of 8 stays one run)
+    w->sub = per >= 128 ? 64 : per >= 64 ? 32 : (per >= 48 || per < 16) ? 16 : 8;
     w->S = (per + w->sub - 1) / w->sub;
     // by groups once they fill the chip's 512 resident blocks (2 per CU), by runs below that
     const long group_blocks = (long)B * ((Lloc + 31) / 32) * w->G;
