@@ -20,6 +20,10 @@ def main():
     sources = [os.path.join(src, "phyloformer_amd", "csrc", f) for f in ("pf_lib.hip", "pf_hostio.cpp")]
     sched = [] if "--default-sched" in args else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
     args = [a for a in args if a != "--default-sched"]
+    if "--sched" in args:                       # another scheduling strategy: --sched max-ilp
+        k = args.index("--sched")
+        sched = ["-mllvm", f"-amdgpu-sched-strategy={args[k + 1]}"]
+        del args[k:k + 2]
     cmd = [B.hipcc_path(), f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize",
            "-Wno-unused-value", *sched, *args, *sources, "-o", out, "-ldl"]
     res = subprocess.run(cmd, capture_output=True, text=True)
