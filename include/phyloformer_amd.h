@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -55,7 +55,8 @@ typedef enum pf_status {
     PF_EHIP = -2,    /* a HIP runtime call or kernel launch failed */
     PF_ERCCL = -3,   /* RCCL missing or a collective failed */
     PF_ENOMEM = -4,  /* device or host allocation failed */
-    PF_ESTATE = -5   /* call not valid in the handle's current state */
+    PF_ESTATE = -5,  /* call not valid in the handle's current state */
+    PF_EIO = -6      /* a file could not be read (pf_fasta_batch_load: detail = errno) */
 } pf_status;
 
 /* Flat fp32 weight blob.  Order (phyloformer_amd/weights.py::blob_layout):
@@ -85,6 +86,14 @@ uint64_t pf_blob_len(int32_t n_blocks, int32_t n_heads, int32_t embed_dim);
 
 int pf_abi_version(void);
 
+/* What this library was built from (ABI 4): a JSON object, static storage -
+ *   {"abi", "arch", "hipcc" (HIP and clang versions), "sched_strategy" ("iterative-ilp" | "default"),
+ *    "sched_fallback" (true when hipcc could not compile pf_lib.hip with the intended strategy and
+ *    phyloformer_amd/build.py was allowed to fall back: 1-7 % slower kernels), "flags" per translation unit,
+ *    "source_hash" (sha256/16 over csrc/ + include/), "kernel_hash" (pf_device.hip.h + the flags of its unit)}.
+ * bench.py copies it into its line and refuses PMC traffic figures taken with another kernel_hash. */
+const char* pf_build_info(void);
+
 /* Create a handle on HIP device `device`: uploads the weights, builds the
  * embedding table and the bf16 hi/lo MFMA operand images.  Fails with PF_EHIP
  * if no gfx950 device is present: there is no CPU fallback. */
@@ -111,6 +120,11 @@ const char* pf_last_error(const pf_handle_t* h);
  *                      default 0: block 0's kernels form it from the embedding table on the fly
  *   "embed_mfma" int   1 = compute block 0's row statistics with the MFMA kernel (k_main<FIRST>) instead of
  *                      the residue-pair table lookup (k_embed); cross-check only, same results to fp32 noise
+ *   "precise"    int   which alignments take the float64 path (csrc/pf_precise.hip.h): -1 (default) = chosen from
+ *                      the alignment's shape (fewer than 16 sites, at most 4 sequences, or fewer than 1024
+ *                      pair-site tokens: input on which the fp32 reference itself is ill-conditioned and the
+ *                      split-bf16 kernels cannot hold 1e-4), 0 = never, 1 = always (tests: the float64 path
+ *                      against a float64 oracle on any shape).  The choice never depends on the batch.
  */
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
 
@@ -186,6 +200,7 @@ int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double
  *             (x0 = embedding + pair expansion, x<k> = output of block k-1)
  *   "srow<k>" float [B][P][72]   row statistics feeding block k
  *   "ctx<k>"  float [B][Lloc][64] column context of block k
+ * (the float64 path keeps only "x<k>", k >= 1, narrowed to float)
  * Returns the number of floats written (<= cap) or a negative status. */
 int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap);
 
@@ -261,6 +276,31 @@ int pf_parse_fasta(const char* data, int64_t len, uint8_t* idx, int64_t idx_cap,
  * Returns the text length in bytes (not NUL-terminated); nothing past `cap` is written, so a
  * first call with out = NULL, cap = 0 sizes the buffer. */
 int64_t pf_format_phylip(const float* preds, int32_t n, const char* const* ids, char* out, int64_t cap);
+/* Same with explicit id lengths (ids may then hold NUL bytes, as the reference's str ids may). */
+int64_t pf_format_phylip_n(const float* preds, int32_t n, const char* const* ids, const int64_t* id_lens, char* out,
+                           int64_t cap);
+
+/* ---- many files per call, on native threads (ABI 4) -----------------------------------------------
+ *
+ * The CLI loop (infer_alns.py:97-117) opens, parses, formats and writes one small file per alignment.
+ * pf_fasta_batch_load reads and parses `count` files on up to `threads` native threads (pf_parse_fasta's
+ * rules and status codes per file; PF_EIO with detail = errno when a file cannot be read) into a
+ * library-owned batch object; pf_fasta_batch_infos fills per-file arrays of length count;
+ * pf_fasta_batch_gather copies the residue indices of `count` (batch, file) entries, all of shape n x l,
+ * into dst [count][n][l] - the input of pf_forward; pf_phylip_write_batch formats preds [count][n(n-1)/2]
+ * as pf_format_phylip does, with the sequence ids the batch objects hold, and writes out_paths[k] on up to
+ * `threads` threads: status[k] = 0 or -errno.  A batch object is immutable after load: any number of threads
+ * may read it; free it once, after the last use. */
+typedef struct pf_fasta_batch pf_fasta_batch_t;
+int pf_fasta_batch_load(const char* const* paths, int32_t count, int32_t threads, pf_fasta_batch_t** out);
+void pf_fasta_batch_free(pf_fasta_batch_t* b);
+int32_t pf_fasta_batch_count(const pf_fasta_batch_t* b);
+int pf_fasta_batch_infos(const pf_fasta_batch_t* b, int32_t* status, int32_t* n, int32_t* l, int64_t* detail);
+int pf_fasta_batch_id(const pf_fasta_batch_t* b, int32_t file, int32_t seq, const char** id, int64_t* len);
+int pf_fasta_batch_gather(const pf_fasta_batch_t* const* batches, const int32_t* file_idx, int32_t count, int32_t n,
+                          int32_t l, uint8_t* dst);
+int pf_phylip_write_batch(const pf_fasta_batch_t* const* batches, const int32_t* file_idx, int32_t count, int32_t n,
+                          const float* preds, const char* const* out_paths, int32_t threads, int32_t* status);
 
 #ifdef __cplusplus
 }

@@ -5,21 +5,47 @@
 hipcc cross-compiles without a GPU, so this also runs in the build container.
 The shared object lands next to this file and is git-ignored; it travels to
 the GPU box with the working-tree snapshot.
+
+Every translation unit is compiled on its own and the objects are linked together with a generated
+``pf_build_info.cpp``: the library can say which compiler, which flags (including the scheduling strategy that
+REALLY compiled ``pf_lib.hip``) and which sources it was built from (``pf_build_info()``, ABI 4) - ``bench.py``
+copies that onto its JSON line.
 """
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import shutil
 import subprocess
 import sys
+import tempfile
+from typing import Dict, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libphyloformer_amd.so")
-SOURCES = [os.path.join(CSRC, "pf_lib.hip"), os.path.join(CSRC, "pf_hostio.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "pf_device.hip.h"), os.path.join(CSRC, "pf_mha.hip.h"),
-                  os.path.join(os.path.dirname(HERE), "include", "phyloformer_amd.h")]
 ARCH = "gfx950"
+
+# -amdgpu-sched-strategy=iterative-ilp: with the default (max-occupancy) strategy hipcc sinks the software-
+# pipelined LDS fragment reads of k_main's hidden loop down to their first use (read - wait - MFMA, one at a
+# time, a single fragment buffer) whenever code outside the loop changes - +7 % on the loop between two builds
+# with identical loop source (round 3, DESIGN.md section 9); the iterative ILP strategy keeps the read pairs
+# ahead of the MFMAs and is 1.3 % faster on the forward (k_colstats gains too).
+SCHED = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# source -> extra flags.  pf_precise.hip (float64 kernels) is its own translation unit with the default
+# strategy: iterative-ilp crashes hipcc's register allocator on it (ROCm 7.2, kp_head).
+UNITS: Dict[str, List[str]] = {
+    "pf_lib.hip": [f"--offload-arch={ARCH}", "-fno-slp-vectorize"] + SCHED,
+    "pf_precise.hip": [f"--offload-arch={ARCH}"],
+    "pf_hostio.cpp": [],
+}
+HEADERS = ["pf_device.hip.h", "pf_mha.hip.h", "pf_precise.hip.h", "pf_precise_host.hip.h"]
+# what decides the bits and the speed of the dominant kernels (k_main, k_colstats): the PMC traffic file under
+# profiles/ is tied to this hash (bench.py: a mismatch means the counters are stale -> traffic null)
+KERNEL_FILES = ["pf_device.hip.h"]
 
 
 def hipcc_path() -> str:
@@ -29,46 +55,109 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def _deps() -> List[str]:
+    return ([os.path.join(CSRC, u) for u in UNITS] + [os.path.join(CSRC, h) for h in HEADERS] +
+            [os.path.join(INCLUDE, "phyloformer_amd.h"), os.path.abspath(__file__)])
+
+
+def is_stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    # -amdgpu-sched-strategy=iterative-ilp: with the default (max-occupancy) strategy hipcc sinks the software-
-    # pipelined LDS fragment reads of k_main's hidden loop down to their first use (read - wait - MFMA, one at a
-    # time, a single fragment buffer) whenever code outside the loop changes - +7 % on the loop between two builds
-    # with identical loop source (round 3); the iterative ILP strategy keeps the read pairs
-    # ahead of the MFMAs and is 1.3 % faster on the forward (k_colstats gains too).
-    sched = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
-    base = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-            "-fno-slp-vectorize", "-Wno-unused-value"]
-    tail = [*SOURCES, "-o", LIB + ".tmp", "-ldl"]
-    if verbose:
-        tail.append("-Rpass-analysis=kernel-resource-usage")
-    res = None
-    # the iterative-ILP strategy is a less travelled path of the compiler (it crashed on one variant of k_rowfin
-    # during round 3): if hipcc fails with it, build with the default strategy rather than not at all
-    for flags in (sched, []):
-        cmd = base + flags + tail
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
+def _sha(paths: List[str], extra: str = "") -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    h.update(extra.encode())
+    return h.hexdigest()[:16]
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over every source and header the library is built from."""
+    return _sha([d for d in _deps() if not d.endswith("build.py")])
+
+
+def kernel_hash(lib_flags: Optional[List[str]] = None) -> str:
+    """Hash of what decides k_main / k_colstats: their source and the flags pf_lib.hip is compiled with."""
+    flags = COMMON + (UNITS["pf_lib.hip"] if lib_flags is None else lib_flags)
+    return _sha([os.path.join(CSRC, f) for f in KERNEL_FILES], " ".join(flags))
+
+
+def _hipcc_version(hipcc: str) -> str:
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return "unknown"
+    hip = next((l.split(":", 1)[1].strip() for l in out.splitlines() if l.startswith("HIP version")), "?")
+    clang = next((l.strip() for l in out.splitlines() if "clang version" in l), "?")
+    return f"HIP {hip}; {clang}"[:200]
+
+
+def build(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
+    """Compile and link.  ``PF_ALLOW_SCHED_FALLBACK=1`` lets a hipcc that cannot compile pf_lib.hip with the
+    iterative-ILP strategy fall back to the default one (1-7 % slower kernels) - the library
+    then reports ``sched_fallback: true`` and bench.py carries it; without the variable the build FAILS.
+    ``PF_BUILD_FORCE_FALLBACK=1`` (tests) takes the fallback without trying."""
+    if not force and not is_stale(out):
+        return out
+    hipcc = hipcc_path()
+    allow = os.environ.get("PF_ALLOW_SCHED_FALLBACK") == "1"
+    forced = os.environ.get("PF_BUILD_FORCE_FALLBACK") == "1"
+    tmp = tempfile.mkdtemp(prefix="pf_build_")
+    try:
+        objs, used = [], {}
+        for unit, extra in UNITS.items():
+            attempts = [extra]
+            if unit == "pf_lib.hip":
+                no_sched = [f for f in extra if f not in SCHED]
+                attempts = [no_sched] if forced else ([extra, no_sched] if allow else [extra])
+            obj = os.path.join(tmp, unit + ".o")
+            res = None
+            for flags in attempts:
+                cmd = [hipcc, *COMMON, *flags, "-c", os.path.join(CSRC, unit), "-o", obj]
+                if verbose:
+                    cmd.append("-Rpass-analysis=kernel-resource-usage")
+                    print(" ".join(cmd), file=sys.stderr)
+                res = subprocess.run(cmd, capture_output=True, text=True)
+                if res.returncode == 0:
+                    used[unit] = flags
+                    break
+                sys.stderr.write(f"phyloformer_amd.build: hipcc failed on {unit} with {' '.join(flags)}\n")
+            if verbose or res.returncode != 0:
+                sys.stderr.write(res.stdout + res.stderr)
+            if res.returncode != 0:
+                hint = ("" if unit != "pf_lib.hip" or allow else
+                        " (set PF_ALLOW_SCHED_FALLBACK=1 to accept the default scheduling strategy: slower kernels)")
+                raise RuntimeError(f"hipcc failed on {unit} with exit code {res.returncode}{hint}")
+            objs.append(obj)
+        fallback = not all(f in used["pf_lib.hip"] for f in SCHED)
+        if fallback:
+            sys.stderr.write("phyloformer_amd.build: WARNING - pf_lib.hip was compiled with hipcc's DEFAULT scheduling "
+                             "strategy (sched_fallback: true in pf_build_info)\n")
+        info = {
+            "abi": 4, "arch": ARCH, "hipcc": _hipcc_version(hipcc),
+            "sched_strategy": "default" if fallback else "iterative-ilp", "sched_fallback": fallback,
+            "flags": {u: " ".join(COMMON + f) for u, f in used.items()},
+            "source_hash": source_hash(), "kernel_hash": kernel_hash(used["pf_lib.hip"]),
+        }
+        gen = os.path.join(tmp, "pf_build_info.cpp")
+        with open(gen, "w") as fh:
+            text = json.dumps(info, sort_keys=True)
+            fh.write('extern "C" const char* pf_build_info(void) { return R"PFBI(' + text + ')PFBI"; }\n')
+        cmd = [hipcc, *COMMON, "-shared", *objs, gen, "-o", out + ".tmp", "-ldl"]
         res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode == 0:
-            break
-        if flags:
-            sys.stderr.write("phyloformer_amd.build: hipcc failed with " + " ".join(flags) +
-                             "; retrying with the default scheduling strategy\n")
-    if verbose or res.returncode != 0:
-        sys.stderr.write(res.stdout + res.stderr)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed with exit code {res.returncode}")
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError(f"link failed with exit code {res.returncode}")
+        os.replace(out + ".tmp", out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":

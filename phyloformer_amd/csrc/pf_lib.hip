@@ -33,6 +33,7 @@
 #include "../../include/phyloformer_amd.h"
 #include "pf_device.hip.h"
 #include "pf_mha.hip.h"
+#include "pf_precise.hip.h"
 
 using namespace pfk;
 
@@ -110,7 +111,7 @@ bool load_rccl(std::string& err) {
     err = g_rccl_err;
     return false;
 }
-constexpr int NCCL_FLOAT = 7, NCCL_SUM = 0;
+constexpr int NCCL_FLOAT = 7, NCCL_DOUBLE = 8, NCCL_SUM = 0;
 
 // ---- bf16 helpers (host) --------------------------------------------------------------------
 uint16_t f2bf(float f) {  // round to nearest even
@@ -217,8 +218,17 @@ struct BlockDev {
 
 struct ProfSlot { int kid; hipEvent_t a, b; };
 const char* const KNAMES[] = {"embed", "rowfin", "colstats", "colfin", "main", "allreduce",
-                              "mha_qkv", "mha_attn", "mha_out"};
-enum { K_EMBED = 0, K_ROWFIN, K_COLSTATS, K_COLFIN, K_MAIN, K_ALLREDUCE, K_MHA_QKV, K_MHA_ATTN, K_MHA_OUT, K_COUNT };
+                              "mha_qkv", "mha_attn", "mha_out", "precise"};
+enum { K_EMBED = 0, K_ROWFIN, K_COLSTATS, K_COLFIN, K_MAIN, K_ALLREDUCE, K_MHA_QKV, K_MHA_ATTN, K_MHA_OUT, K_PRECISE, K_COUNT };
+
+// weights of the float64 path (pf_precise.hip.h), widened and transposed at pf_create
+struct PreciseWeights {
+    double* blob = nullptr;
+    const double* table = nullptr;                 // [22][64] relu(W + b), formed in double
+    std::vector<pfp::AttnW> row, col;
+    std::vector<pfp::FfnW> ffn;
+    const double *hw = nullptr, *hb = nullptr;
+};
 
 }  // namespace
 
@@ -282,6 +292,10 @@ struct pf_handle {
     std::map<std::string, std::vector<float>> taps;
     // A/B runs: PF_ROW_TILES / PF_FLAT_TILES, read once at creation (-1 = choose from the shape)
     int tile_force = -1;
+    // float64 path for ill-conditioned shapes (pf_precise.hip.h): option "precise" -1 = by shape, 0 = never, 1 = always
+    int precise = -1;
+    PreciseWeights pw;
+    char* wsp = nullptr; size_t wsp_bytes = 0;
     // sticky "residue byte > 21 seen" flag: pinned host memory the kernels write through its device alias
     unsigned* bad_idx_host = nullptr;
     unsigned* bad_idx_dev = nullptr;
@@ -666,14 +680,14 @@ int save_tap(pf_handle* h, const std::string& name, const float* dptr, size_t n)
 
 // Collectives belong to the site-sharded entry points only: pf_forward / pf_forward_device on a handle
 // that carries a communicator (alignment-level data parallelism) must not reduce across ranks.
-int allreduce(pf_handle* h, float* buf, size_t count) {
+int allreduce(pf_handle* h, void* buf, size_t count, int dtype = NCCL_FLOAT) {
     if (!h->sharded_call) return PF_OK;
     if (h->world <= 1 && !h->comm[0]) return PF_OK;
     if (!h->comm[0]) return fail(h, PF_ESTATE, "sharded forward on %d ranks needs pf_comm_init", h->world);
     ProfScope ps(h, K_ALLREDUCE);
     void* comm = h->comm[(h->cur == h->stream2 && h->stream2) ? 1 : 0];    // the stream's own communicator
     ++h->coll_calls;
-    int rc = g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT, NCCL_SUM, comm, h->cur);
+    int rc = g_rccl.AllReduce(buf, buf, count, dtype, NCCL_SUM, comm, h->cur);
     if (rc != 0)
         return fail(h, PF_ERCCL, "ncclAllReduce failed: %s",
                     g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
@@ -933,6 +947,8 @@ int forward_chunk(pf_handle* h, const uint8_t* d_idx, int B, int N, int Lloc, in
     return PF_OK;
 }
 
+#include "pf_precise_host.hip.h"
+
 int check_dims(pf_handle* h, int B, int N, int Lloc, int L_total) {
     if (!h) return PF_EINVAL;
     if (h->n_blocks == 0) return fail(h, PF_ESTATE, "handle was created without Phyloformer weights (pf_create_bare)");
@@ -1002,6 +1018,7 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
         // tests/test_gpu_sharding.py runs it on one GPU.)
         if (h->n_blocks == 0) return fail(h, PF_ESTATE, "handle was created without Phyloformer weights (pf_create_bare)");
         HIPCHK(h, hipSetDevice(h->device));
+        if (use_precise(h, N, L_total)) return forward_device_precise(h, d_idx, B, N, l_begin, l_end, L_total, d_out);
         const int P0 = N * (N - 1) / 2;
         const int cb0 = chunk_batch(h, B, P0, (L_total + h->world - 1) / h->world);
         ForwardScope scope(h, true);
@@ -1044,6 +1061,7 @@ int forward_device_impl(pf_handle* h, const uint8_t* d_idx, int B, int N, int l_
     if (rc) return rc;
     if (l_begin < 0 || l_end > L_total) return fail(h, PF_EINVAL, "site range [%d, %d) outside [0, %d)", l_begin, l_end, L_total);
     HIPCHK(h, hipSetDevice(h->device));
+    if (use_precise(h, N, L_total)) return forward_device_precise(h, d_idx, B, N, l_begin, l_end, L_total, d_out);
     const int P = N * (N - 1) / 2;
     // every rank must cut the batch into the same chunks (one all-reduce sequence per chunk), so the
     // chunk size is derived from the largest shard, not from this rank's own
@@ -1199,6 +1217,7 @@ int pf_create(const pf_weights_t* w, int device, pf_handle_t** out) {
     if (rc) return rc;
     h->n_blocks = w->n_blocks;
     rc = prepare_weights(h, w);
+    if (!rc) rc = prepare_precise_weights(h, w, &h->pw);
     if (rc) g_create_error = h->err;
     if (rc) { pf_destroy(h); return rc; }
     *out = h;
@@ -1218,6 +1237,7 @@ int pf_destroy(pf_handle_t* h) {
     if (h->pair_j) hipFree(h->pair_j);
     if (h->ws) hipFree(h->ws);
     if (h->ws2) hipFree(h->ws2);
+    if (h->wsp) hipFree(h->wsp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -1245,6 +1265,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "reserve_cus") h->reserve_cus = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128));
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
+    else if (k == "precise") h->precise = value < 0 ? -1 : (value != 0);
     else if (k == "phase_prof") {
         if (value && !h->phase_prof) { HIPCHK(h, hipMalloc((void**)&h->phase_prof, 64)); h->owned.push_back(h->phase_prof); }
         if (h->phase_prof) HIPCHK(h, hipMemset(h->phase_prof, 0, 64));
@@ -1450,6 +1471,7 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
     if (rc) return rc;
     if (nshards < 1 || nshards > 64 || !idx || !out) return fail(h, PF_EINVAL, "bad shard count or null buffer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (use_precise(h, N, L)) return forward_shards_emulated_precise(h, idx, B, N, L, nshards, out);
     if ((rc = ensure_pairs(h, N))) return rc;
     const int P = N * (N - 1) / 2;
     const int step = (L + nshards - 1) / nshards;

@@ -17,7 +17,7 @@ from .weights import ModelWeights
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libphyloformer_amd.so")
-ABI_VERSION = 3            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
+ABI_VERSION = 4            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
 UNIQUE_ID_BYTES = 256      # PF_UNIQUE_ID_BYTES: two ncclUniqueIds, one per communicator / stream
 
 PF_OK, PF_EINVAL, PF_EHIP, PF_ERCCL, PF_ENOMEM, PF_ESTATE = 0, -1, -2, -3, -4, -5
@@ -40,6 +40,7 @@ class pf_weights_t(C.Structure):
 _H = C.c_void_p
 SIGNATURES = {
     "pf_abi_version": (C.c_int, []),
+    "pf_build_info": (C.c_char_p, []),
     "pf_blob_len": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
     "pf_create": (C.c_int, [C.POINTER(pf_weights_t), C.c_int, C.POINTER(_H)]),
     "pf_destroy": (C.c_int, [_H]),
@@ -76,6 +77,15 @@ SIGNATURES = {
     "pf_parse_fasta": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "pf_format_phylip": (C.c_int64, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_char_p, C.c_int64]),
+    "pf_format_phylip_n": (C.c_int64, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p, C.c_int64]),
+    "pf_fasta_batch_load": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pf_fasta_batch_free": (None, [C.c_void_p]),
+    "pf_fasta_batch_count": (C.c_int32, [C.c_void_p]),
+    "pf_fasta_batch_infos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_fasta_batch_id": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "pf_fasta_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pf_phylip_write_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.POINTER(C.c_char_p), C.c_int32, C.c_void_p]),
     "pf_forward_shards_emulated": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_void_p]),
 }
@@ -103,6 +113,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def build_info(path: Optional[str] = None) -> Dict[str, object]:
+    """What the loaded library was built from (``pf_build_info``, ABI 4): compiler, flags, the scheduling
+    strategy that really compiled the kernels, source and kernel hashes.  Needs no device."""
+    import json
+    return json.loads(load_library(path).pf_build_info().decode())
 
 
 def _u8(a: np.ndarray) -> np.ndarray:

@@ -9,6 +9,7 @@ beside the GPU instead of in front of it.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -16,6 +17,28 @@ import numpy as np
 from .engine import load_library
 
 PF_FASTA_EBYTE, PF_FASTA_ERAGGED, PF_FASTA_ENOHEADER, PF_FASTA_EEMPTY, PF_FASTA_ECAP = -16, -17, -18, -19, -20
+
+
+PF_EIO = -6
+
+
+def parse_error(rc: int, l: int, detail: int, path: str = "") -> "BaseException | None":
+    """The exception the reference raises where pf_parse_fasta returns ``rc`` (None = a valid alignment)."""
+    if rc == PF_FASTA_EBYTE:
+        return KeyError(int(detail))
+    if rc == PF_FASTA_ENOHEADER:
+        return IndexError("sequence data before the first '>' header")
+    if rc == PF_FASTA_EEMPTY or (rc == 0 and l == 0):
+        # same class as the reference, whose one_hot refuses the empty tensor (data.py:28)
+        return RuntimeError("no residues found (empty alignment)")
+    if rc == PF_FASTA_ERAGGED:
+        return ValueError("expected sequences of equal length")
+    if rc == PF_EIO:
+        import os
+        return OSError(int(detail), os.strerror(int(detail)), path)
+    if rc != 0:
+        return RuntimeError(f"pf_parse_fasta failed with status {rc}")
+    return None
 
 
 def parse_fasta(data: bytes) -> Tuple[np.ndarray, List[str]]:
@@ -27,17 +50,9 @@ def parse_fasta(data: bytes) -> Tuple[np.ndarray, List[str]]:
     n, l, detail = C.c_int32(0), C.c_int32(0), C.c_int64(0)
     rc = lib.pf_parse_fasta(data, len(data), idx.ctypes.data, idx.size, spans.ctypes.data, n_max,
                             C.byref(n), C.byref(l), C.byref(detail))
-    if rc == PF_FASTA_EBYTE:
-        raise KeyError(int(detail.value))
-    if rc == PF_FASTA_ENOHEADER:
-        raise IndexError("sequence data before the first '>' header")
-    if rc == PF_FASTA_EEMPTY or (rc == 0 and l.value == 0):
-        # same class as the reference, whose one_hot refuses the empty tensor (data.py:28)
-        raise RuntimeError("no residues found (empty alignment)")
-    if rc == PF_FASTA_ERAGGED:
-        raise ValueError("expected sequences of equal length")
-    if rc != 0:
-        raise RuntimeError(f"pf_parse_fasta failed with status {rc}")
+    exc = parse_error(rc, l.value, detail.value)
+    if exc is not None:
+        raise exc
     ids = [data[int(spans[2 * i]):int(spans[2 * i] + spans[2 * i + 1])].decode("utf8") for i in range(n.value)]
     return idx[:n.value * l.value].reshape(n.value, l.value).copy(), ids
 
@@ -55,16 +70,98 @@ def format_phylip(preds: np.ndarray, ids: Sequence[str]) -> bytes:
     if p.size != n * (n - 1) // 2:
         raise ValueError(f"expected {n * (n - 1) // 2} distances for {n} sequences, got {p.shape}")
     enc = [s.encode("utf8") for s in ids]
-    if any(b"\0" in e for e in enc):
-        raise ValueError("sequence id contains a NUL byte")
     arr = (C.c_char_p * n)(*enc)
-    cap = sum(len(e) for e in enc) + n * (n * 24 + 2) + 32
+    lens = np.array([len(e) for e in enc], dtype=np.int64)      # explicit lengths: an id may hold NUL bytes
+    cap = int(lens.sum()) + n * (n * 24 + 2) + 32
     buf = C.create_string_buffer(cap)
-    w = lib.pf_format_phylip(p.ctypes.data, n, arr, buf, cap)
+    w = lib.pf_format_phylip_n(p.ctypes.data, n, arr, lens.ctypes.data, buf, cap)
     if w < 0:
         raise RuntimeError(f"pf_format_phylip failed with status {w}")
     if w > cap:                                      # astronomically large distances
         cap = int(w)
         buf = C.create_string_buffer(cap)
-        w = lib.pf_format_phylip(p.ctypes.data, n, arr, buf, cap)
+        w = lib.pf_format_phylip_n(p.ctypes.data, n, arr, lens.ctypes.data, buf, cap)
     return buf.raw[:w]
+
+
+class FastaBatch:
+    """``pf_fasta_batch_load``: a list of FASTA files read and parsed on native threads (GIL released for the
+    whole call).  The parsed alignments stay in library memory; ``gather`` copies the residue indices of a
+    same-shaped selection into one ``uint8[B, N, L]`` array and ``write_phylip`` formats and writes their
+    distance matrices with the ids the batch holds - Python never touches residues or ids on that path."""
+
+    def __init__(self, paths: Sequence[str], threads: int = 8):
+        self._lib = load_library()
+        self.paths = list(paths)
+        self._h = C.c_void_p()
+        enc = [os.fsencode(p) for p in self.paths]
+        arr = (C.c_char_p * len(enc))(*enc)
+        rc = self._lib.pf_fasta_batch_load(arr, len(enc), int(threads), C.byref(self._h))
+        if rc != 0:
+            raise MemoryError("pf_fasta_batch_load failed") if rc == -4 else RuntimeError(f"pf_fasta_batch_load: status {rc}")
+        k = len(enc)
+        self.status = np.empty(k, np.int32)
+        self.n = np.empty(k, np.int32)
+        self.l = np.empty(k, np.int32)
+        self.detail = np.empty(k, np.int64)
+        self._lib.pf_fasta_batch_infos(self._h, self.status.ctypes.data, self.n.ctypes.data, self.l.ctypes.data,
+                                       self.detail.ctypes.data)
+
+    def __len__(self):
+        return len(self.paths)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_fasta_batch_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def error(self, i: int) -> "BaseException | None":
+        """What ``load_alignment`` raises for file ``i`` (None: a valid alignment)."""
+        return parse_error(int(self.status[i]), int(self.l[i]), int(self.detail[i]), self.paths[i])
+
+    def ids(self, i: int) -> List[str]:
+        out, p, ln = [], C.c_void_p(), C.c_int64()
+        for s in range(int(self.n[i])):
+            if self._lib.pf_fasta_batch_id(self._h, i, s, C.byref(p), C.byref(ln)) != 0:
+                raise IndexError((i, s))
+            out.append(C.string_at(p, ln.value).decode("utf8"))
+        return out
+
+    def indices(self, i: int) -> np.ndarray:
+        return gather([(self, i)], int(self.n[i]), int(self.l[i]))[0]
+
+
+def gather(entries: Sequence[Tuple["FastaBatch", int]], n: int, l: int) -> np.ndarray:
+    """``uint8[B, N, L]`` of the ``(batch, file)`` entries, all of shape ``(n, l)``."""
+    lib = load_library()
+    k = len(entries)
+    hs = (C.c_void_p * k)(*[e[0]._h for e in entries])
+    fi = np.array([e[1] for e in entries], dtype=np.int32)
+    out = np.empty((k, n, l), dtype=np.uint8)
+    rc = lib.pf_fasta_batch_gather(hs, fi.ctypes.data, k, n, l, out.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"pf_fasta_batch_gather: status {rc} (entries of another shape than {n} x {l}?)")
+    return out
+
+
+def write_phylip(entries: Sequence[Tuple["FastaBatch", int]], n: int, preds: np.ndarray, out_paths: Sequence[str],
+                 threads: int = 8) -> None:
+    """Format ``preds[B, P]`` and write ``out_paths`` on native threads; ``OSError`` for the first file that failed."""
+    lib = load_library()
+    k = len(entries)
+    p = np.ascontiguousarray(np.asarray(preds, dtype=np.float32).reshape(k, -1))
+    if p.shape[1] != n * (n - 1) // 2 or len(out_paths) != k:
+        raise ValueError(f"expected {k} x {n * (n - 1) // 2} distances and {k} paths")
+    hs = (C.c_void_p * k)(*[e[0]._h for e in entries])
+    fi = np.array([e[1] for e in entries], dtype=np.int32)
+    paths = (C.c_char_p * k)(*[os.fsencode(q) for q in out_paths])
+    status = np.zeros(k, dtype=np.int32)
+    rc = lib.pf_phylip_write_batch(hs, fi.ctypes.data, k, n, p.ctypes.data, paths, int(threads), status.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"pf_phylip_write_batch: status {rc}")
+    bad = np.flatnonzero(status)
+    if bad.size:
+        e = -int(status[bad[0]])
+        raise OSError(e, os.strerror(e), out_paths[int(bad[0])])

@@ -48,6 +48,11 @@ import numpy as np
 TOKEN_BUDGET = 16 * 1770 * 500
 
 
+# files per native load call (FastaBatch): enough to amortise a thread-pool start over many small files, few enough
+# that the first launch does not wait for the whole directory
+FILES_PER_LOAD = 256
+
+
 def auto_batch(n_seqs: int, n_sites: int, max_batch: int = 4096, token_budget: int = TOKEN_BUDGET) -> int:
     """Alignments per launch for shape ``(N, L)``: fill the token budget, at least 1."""
     tokens = max(1, n_seqs * (n_seqs - 1) // 2 * n_sites)
@@ -118,8 +123,14 @@ class DirectoryRunner:
                 fh.write(neighbor_joining(dm.astype("float64"), ids))
 
     def _launch(self, engine, shape: Tuple[int, int], group: list, writers: ThreadPoolExecutor, pending: deque):
+        native = group[0][2] is None              # entries of _feed_native: (path, (FastaBatch, file), None)
         t0 = time.perf_counter()
-        preds = engine.forward(np.stack([g[1] for g in group]))
+        if native:
+            from .hostio import gather
+            batch = gather([g[1] for g in group], shape[0], shape[1])
+        else:
+            batch = np.stack([g[1] for g in group])
+        preds = engine.forward(batch)
         dt = time.perf_counter() - t0
         with self._lock:
             self.stats["forward_s"] += dt
@@ -127,19 +138,28 @@ class DirectoryRunner:
             self.stats["alignments"] += len(group)
             key = f"{shape[0]}x{shape[1]}"
             self.stats["shapes"][key] = self.stats["shapes"].get(key, 0) + len(group)
-            for (path, _idx, ids), pred in zip(group, preds):
-                pending.append(writers.submit(self._write, path, pred, ids))
+            if native:
+                pending.append(writers.submit(self._write_native, shape[0], group, preds))
+            else:
+                for (path, _idx, ids), pred in zip(group, preds):
+                    pending.append(writers.submit(self._write, path, pred, ids))
             if self.progress is not None:
                 self.progress(len(group))
             drain = []
             # bound the write queue so results do not pile up in memory
-            while len(pending) > 8 * self.io_threads + len(group):
+            while len(pending) > 8 * self.io_threads + (1 if native else len(group)):
                 drain.append(pending.popleft())
         t0 = time.perf_counter()
         for f in drain:
             f.result()
         with self._lock:
             self.stats["write_wait_s"] += time.perf_counter() - t0
+
+    def _write_native(self, n: int, group: list, preds: np.ndarray):
+        """``<stem>.phy`` of a whole launch: formatted and written on native threads (infer_alns.py:105-117)."""
+        from .hostio import write_phylip
+        outs = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.phy") for g in group]
+        write_phylip([g[1] for g in group], n, preds, outs, self.io_threads)
 
     def _gpu_worker(self, engine, jobs: "queue.Queue", writers, pending, errors: list):
         while True:
@@ -155,14 +175,21 @@ class DirectoryRunner:
 
     # -- driver -----------------------------------------------------------------------------
     def run(self, paths: Sequence[str]) -> dict:
-        for p in paths:
+        """Process ``paths`` in the given order.  Side effects on a bad entry are the reference's
+        (infer_alns.py:97-117 handles one file after the other): every alignment in front of the first entry
+        without a FASTA extension (``ValueError``, :100-103), or of the first file that does not parse
+        (``KeyError`` / ``ValueError`` / ... from ``load_alignment``, :108), is computed and written; nothing
+        behind it is; then the exception is raised."""
+        paths = list(paths)
+        deferred: Optional[BaseException] = None
+        for k, p in enumerate(paths):
             if not has_fasta_ext(p):
-                raise ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{p}")
+                deferred = ValueError("Input files must be fasta files (.fa or .fasta). Got " f"{p}")
+                paths = paths[:k]
+                break
         t_start = time.perf_counter()
-        buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
         pending: deque = deque()
         errors: list = []
-        lookahead = max(64, 4 * (self.batch or 64))
         jobs: "queue.Queue" = queue.Queue(maxsize=2 * len(self.engines))
         with ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-load") as loaders, \
                 ThreadPoolExecutor(self.io_threads, thread_name_prefix="pf-write") as writers:
@@ -171,32 +198,9 @@ class DirectoryRunner:
             for w in workers:
                 w.start()
             try:
-                inflight: "deque[Tuple[str, Future]]" = deque()
-                it = iter(paths)
-                exhausted = False
-                while not errors:
-                    while not exhausted and len(inflight) < lookahead:
-                        try:
-                            p = next(it)
-                        except StopIteration:
-                            exhausted = True
-                            break
-                        inflight.append((p, loaders.submit(self._load, p)))
-                    if not inflight:
-                        break
-                    path, fut = inflight.popleft()
-                    t0 = time.perf_counter()
-                    idx, ids = fut.result()          # parser exceptions surface here, as in the reference
-                    self.stats["load_wait_s"] += time.perf_counter() - t0
-                    shape = (int(idx.shape[0]), int(idx.shape[1]))
-                    group = buckets.setdefault(shape, [])
-                    group.append((path, idx, ids))
-                    if len(group) >= (self.batch or auto_batch(*shape)):
-                        jobs.put((shape, group))
-                        buckets[shape] = []
-                for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):
-                    if group and not errors:
-                        jobs.put((shape, group))
+                feed = self._feed_native if (self.native_io and not self.trees) else self._feed_python
+                bad = feed(paths, loaders, jobs, errors)
+                deferred = bad or deferred         # a file that fails to parse sits in front of a bad extension
             finally:
                 for _ in workers:
                     jobs.put(None)
@@ -209,7 +213,89 @@ class DirectoryRunner:
                 pending.popleft().result()
             self.stats["write_wait_s"] += time.perf_counter() - t0
         self.stats["wall_s"] = time.perf_counter() - t_start
+        if deferred is not None:
+            raise deferred
         return self.stats
+
+    def _feed_python(self, paths, loaders, jobs, errors) -> Optional[BaseException]:
+        """One future per file (``--python-io``, ``-t``): parse ahead, bucket by shape, launch full buckets."""
+        buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
+        lookahead = max(64, 4 * (self.batch or 64))
+        inflight: "deque[Tuple[str, Future]]" = deque()
+        it = iter(paths)
+        exhausted = False
+        bad: Optional[BaseException] = None
+        while not errors:
+            while not exhausted and len(inflight) < lookahead:
+                try:
+                    p = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                inflight.append((p, loaders.submit(self._load, p)))
+            if not inflight:
+                break
+            path, fut = inflight.popleft()
+            t0 = time.perf_counter()
+            try:
+                idx, ids = fut.result()          # parser exceptions surface here, as in the reference
+            except Exception as exc:             # noqa: BLE001 - raised by run() once the files in front are written
+                bad = exc
+                for _p, f in inflight:
+                    f.cancel()
+                break
+            finally:
+                self.stats["load_wait_s"] += time.perf_counter() - t0
+            shape = (int(idx.shape[0]), int(idx.shape[1]))
+            group = buckets.setdefault(shape, [])
+            group.append((path, idx, ids))
+            if len(group) >= (self.batch or auto_batch(*shape)):
+                jobs.put((shape, group))
+                buckets[shape] = []
+        for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):
+            if group and not errors:
+                jobs.put((shape, group))
+        return bad
+
+    def _feed_native(self, paths, loaders, jobs, errors) -> Optional[BaseException]:
+        """The fast path: ``FILES_PER_LOAD`` files per native call (read + parsed on ``io_threads`` std::threads,
+        no GIL), two calls in flight ahead of the bucketing; a bucket entry is ``(path, (batch, file), None)``
+        - residues and ids stay in the library until the launch gathers them / the writer formats them."""
+        from .hostio import FastaBatch
+        buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
+        chunks = [paths[k:k + FILES_PER_LOAD] for k in range(0, len(paths), FILES_PER_LOAD)]
+        inflight: "deque[Future]" = deque()
+        nxt = 0
+        bad: Optional[BaseException] = None
+        while not errors and bad is None:
+            while nxt < len(chunks) and len(inflight) < 2:
+                inflight.append(loaders.submit(FastaBatch, chunks[nxt], self.io_threads))
+                nxt += 1
+            if not inflight:
+                break
+            t0 = time.perf_counter()
+            fb = inflight.popleft().result()
+            self.stats["load_wait_s"] += time.perf_counter() - t0
+            ok = (fb.status == 0) & (fb.l > 0)
+            stop = len(fb) if ok.all() else int(np.argmin(ok))
+            if stop < len(fb):
+                bad = fb.error(stop)
+            ns, ls = fb.n.tolist(), fb.l.tolist()
+            for i in range(stop):
+                shape = (ns[i], ls[i])
+                group = buckets.get(shape)
+                if group is None:
+                    group = buckets[shape] = []
+                group.append((fb.paths[i], (fb, i), None))
+                if len(group) >= (self.batch or auto_batch(*shape)):
+                    jobs.put((shape, group))
+                    buckets[shape] = []
+        for f in inflight:
+            f.cancel()
+        for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):
+            if group and not errors:
+                jobs.put((shape, group))
+        return bad
 
 
 class SiteShardedRunner(DirectoryRunner):

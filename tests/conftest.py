@@ -44,10 +44,14 @@ def engines(weights):
     from phyloformer_amd.engine import Engine
     cache = {}
 
-    def get(name="pf"):
-        if name not in cache:
-            cache[name] = Engine(weights(name), device=0)
-        return cache[name]
+    def get(name="pf", precise=-1):
+        """precise: -1 = the product's choice (float64 kernels for ill-conditioned shapes, csrc/pf_precise.hip.h);
+        0 = the default split-bf16 kernels on every shape - what the tests of their tile / group / shard edge
+        cases at small sizes want."""
+        if (name, precise) not in cache:
+            cache[name, precise] = Engine(weights(name), device=0)
+            cache[name, precise].set_option("precise", precise)
+        return cache[name, precise]
     yield get
     for e in cache.values():
         e.close()

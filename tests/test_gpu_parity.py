@@ -79,7 +79,7 @@ def _check(err, scale, what=None):
 def test_tiny_taps_localise_every_kernel(engines, weights, golden):
     g = golden("taps_tiny.npz")
     w = weights("pf").tensors
-    e = engines("pf")
+    e = engines("pf", precise=0)        # the default kernels' taps (5 x 16 would otherwise take the float64 path)
     e.set_option("debug_keep", 1)
     try:
         # per-buffer bounds (relative to the largest reference entry): 3-4 x the measured errors on this
@@ -122,9 +122,11 @@ def test_tiny_taps_localise_every_kernel(engines, weights, golden):
         e.set_option("debug_keep", 0)
 
 
-def test_oracle_parity_small_shapes(engines, weights):
-    """Seeded synthetic alignments incl. ragged tile tails, gaps and the minimum sizes."""
-    e = engines("pf_indel")
+@pytest.mark.parametrize("precise", [0, -1])
+def test_oracle_parity_small_shapes(engines, weights, precise):
+    """Seeded synthetic alignments incl. ragged tile tails, gaps and the minimum sizes - through the default kernels
+    (precise = 0: their edge cases) and as the product routes them (-1: the first four take the float64 path)."""
+    e = engines("pf_indel", precise=precise)
     w = weights("pf_indel").tensors
     for (n, l, gaps, seed) in [(2, 1, False, 1), (3, 31, False, 2), (4, 32, True, 3), (5, 33, True, 4),
                                (7, 65, True, 5), (12, 100, False, 6)]:
@@ -134,16 +136,17 @@ def test_oracle_parity_small_shapes(engines, weights):
         assert got.shape == want.shape == (2, n * (n - 1) // 2)
         # 2-5 sequences is far outside the training distribution: the residual stream reaches
         # |x| ~ 560 and logits ~ 190
-        err, scale = _record(f"oracle {n}x{l}{' gapped' if gaps else ''} pf_indel", got, want,
-                             f64=O.forward_batch(w, idx, dtype=np.float64))
+        err, scale = _record(f"oracle {n}x{l}{' gapped' if gaps else ''} pf_indel{'' if precise else ' (default kernels)'}",
+                             got, want, f64=O.forward_batch(w, idx, dtype=np.float64))
         _check(err, scale, (n, l))
 
 
 def test_oracle_parity_shapes_around_the_kernels_block_sizes(engines, weights):
     """Site counts around the 32-site tile, the 64-site residue block of k_embed and the 16 / 32 / 64-pair
     runs of k_colstats (one group, several groups, a short last group), batched and alone - the lone
-    alignment takes the run-sized column-statistics blocks, the batch the group-sized ones."""
-    e = engines("pf")
+    alignment takes the run-sized column-statistics blocks, the batch the group-sized ones.  Default kernels on
+    every shape (33 x 12 would otherwise take the float64 path)."""
+    e = engines("pf", precise=0)
     w = weights("pf").tensors
     cases = [(9, 63, 1, 11), (9, 64, 2, 12), (9, 65, 1, 13), (6, 127, 3, 14), (6, 129, 1, 15), (17, 40, 1, 16),
              (17, 40, 4, 17), (24, 33, 1, 18), (33, 12, 1, 19), (40, 70, 1, 20)]
@@ -265,6 +268,7 @@ def test_column_statistics_by_groups_or_by_runs_same_bits(weights, golden):
         out = {}
         for fine in (0, 1, -1):
             with Engine(weights("pf"), 0) as e:
+                e.set_option("precise", 0)
                 e.set_option("colstats_fine", fine)
                 out[fine] = e.forward(idx)
         assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[-1])
@@ -406,6 +410,7 @@ def test_flat_tiling_against_row_tiling(weights, golden):
             os.environ["PF_ROW_TILES" if row_tiles else "PF_FLAT_TILES"] = "1"
             try:
                 with Engine(weights("pf"), 0) as e:
+                    e.set_option("precise", 0)
                     out[row_tiles] = e.forward(idx)
                     if not row_tiles:          # flat: an alignment's bits do not depend on its place in the batch
                         assert np.array_equal(np.stack([e.forward(x) for x in idx]), out[0])
@@ -420,8 +425,9 @@ def test_flat_tiling_against_row_tiling(weights, golden):
 def test_shape_sweep_against_oracle(engines, weights):
     """Forty seeded (n_seqs, n_sites, batch) shapes - row lengths on both sides of every tile multiple up to 200, one
     to 105 pairs, i.e. every way a 32-token tile can meet a row end or an alignment end in either tiling - against
-    the oracle (absolute 1e-4), with the same bits one alignment at a time."""
-    e = engines("pf")
+    the oracle (absolute 1e-4), with the same bits one alignment at a time.  Default kernels on every shape: this is
+    their tiling sweep (the product's routing of small shapes is tests/test_gpu_precise.py's soak)."""
+    e = engines("pf", precise=0)
     w = weights("pf").tensors
     rng = np.random.default_rng(2024)
     shapes = [(int(rng.integers(2, 16)), int(rng.integers(1, 201)), int(rng.integers(1, 4))) for _ in range(32)]

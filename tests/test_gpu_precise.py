@@ -1,0 +1,137 @@
+"""-m gpu: the float64 path for ill-conditioned shapes (csrc/pf_precise.hip.h) and the randomised soak of the
+whole accepted input range.
+
+The reference forward (model.py:166-187) and CLI loop (infer_alns.py:95-123) accept any N >= 2, L >= 1.  On alignments
+of a few sites or 2-4 sequences the fp32 reference is itself 3e-5 ... 7e-4 from a float64 evaluation; the default
+split-bf16 kernels cannot hold 1e-4 there, so the host routes those SHAPES to float64 kernels.  Bounds used below:
+  * float64 path against the float64 oracle: 1e-9 (it is the same arithmetic up to summation order);
+  * every accepted input against the fp32 oracle: max(1e-4, 2 x |fp32 oracle - fp64 oracle|).
+"""
+import numpy as np
+import pytest
+
+from oracle import pf_oracle as O
+from phyloformer_amd.msa_sim import simulate_batch
+
+pytestmark = pytest.mark.gpu
+CKPTS = ("pf", "pf_base", "pf_indel", "pf_cherry", "pf_selreg")
+
+
+def _f64(w, idx):
+    return O.forward_batch(w, idx, dtype=np.float64)
+
+
+def test_float64_path_matches_float64_oracle(weights):
+    """Forced onto any shape (option precise = 1) the float64 kernels reproduce the float64 oracle to 1e-9:
+    ragged chunks of the reduce axes (CHUNK = 64 elements), gaps, batches, every checkpoint."""
+    from phyloformer_amd.engine import Engine
+    cases = [("pf", 2, 1, 1, False), ("pf", 3, 2, 2, False), ("pf_indel", 4, 7, 3, True), ("pf_base", 5, 16, 1, False),
+             ("pf_cherry", 12, 65, 2, False), ("pf_selreg", 13, 130, 1, True), ("pf", 24, 33, 1, False),
+             ("pf_indel", 7, 200, 2, True)]
+    worst = 0.0
+    for i, (ck, n, l, b, gaps) in enumerate(cases):
+        idx = simulate_batch(b, n, l, seed=900 + i, gaps=gaps)
+        with Engine(weights(ck), 0) as e:
+            e.set_option("precise", 1)
+            got = e.forward(idx).astype(np.float64)
+            want = _f64(weights(ck).tensors, idx)
+            err = float(np.abs(got - want).max())
+            # the result is narrowed to float once at the end: half an ulp of the largest distance
+            assert err <= 1e-9 + 6e-8 * float(np.abs(want).max()), (ck, n, l, b, err)
+            worst = max(worst, err)
+            if b > 1:       # the same bits one alignment at a time, and through the emulated shards
+                assert np.array_equal(np.stack([e.forward(x) for x in idx]), got.astype(np.float32))
+            sh = e.forward_shards_emulated(idx, 3).astype(np.float64)
+            assert float(np.abs(sh - want).max()) <= 1e-9 + 6e-8 * float(np.abs(want).max())
+    print(f"float64 path vs float64 oracle: worst {worst:.3e}")
+
+
+def test_shape_selection_is_by_shape_only_and_batch_invariant(engines, weights):
+    """Alignments of < 16 sites, <= 4 sequences or < 1024 tokens take the float64 path wherever they travel: alone, in
+    a batch, in a batch cut into workspace chunks - identical bits; larger ones keep the default kernels' bits
+    (precise = 0 gives the same result)."""
+    e = engines("pf")
+    w = weights("pf").tensors
+    for (n, l, b) in [(9, 7, 5), (4, 120, 3), (6, 40, 4), (30, 15, 2)]:          # selected
+        idx = simulate_batch(b, n, l, seed=n * 100 + l)
+        got = e.forward(idx)
+        assert np.array_equal(np.stack([e.forward(x) for x in idx]), got)
+        want = _f64(w, idx)
+        assert float(np.abs(got - want).max()) <= 1e-9 + 6e-8 * float(np.abs(want).max()), (n, l)
+        e.set_option("ws_limit_mb", 1)
+        try:
+            assert np.array_equal(e.forward(idx), got)
+        finally:
+            e.set_option("ws_limit_mb", 24576)
+    for (n, l, b) in [(9, 64, 2), (20, 200, 1), (5, 103, 3)]:                    # not selected: the default kernels
+        idx = simulate_batch(b, n, l, seed=n * 100 + l)
+        got = e.forward(idx)
+        e.set_option("precise", 0)
+        try:
+            assert np.array_equal(e.forward(idx), got)
+        finally:
+            e.set_option("precise", -1)
+
+
+def test_float64_path_site_sharded_over_a_real_communicator(weights):
+    """pf_forward_sharded on a float64-path shape over a single-rank RCCL communicator: n_blocks + 1 = 7 double
+    all-reduces on the main stream (never cut into halves), the bits of pf_forward; an empty site range joins the
+    same 7 collectives with zeros."""
+    from phyloformer_amd.engine import Engine
+    idx = simulate_batch(3, 6, 9, seed=77)
+    with Engine(weights("pf"), 0) as e:
+        want = e.forward(idx)
+        e.set_option("force_rccl", 1)
+        e.comm_init(e.unique_id(), 0, 1)
+        e.profile_reset()
+        got = e.forward_sharded(idx, 0, 9, 9)
+        assert e.profile_get("collectives")[0] == 7
+        assert np.array_equal(got, want)
+        e.profile_reset()
+        zero = e.forward_sharded(np.zeros((3, 6, 0), np.uint8), 9, 9, 9)
+        assert e.profile_get("collectives")[0] == 7 and not zero.any()
+        assert np.array_equal(e.forward(idx), want)
+
+
+def _soak_cases(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    ns = [2, 3, 4, 5, 6, 7, 9, 12, 17, 24, 33, 40]
+    ls = [1, 2, 3, 4, 5, 7, 9, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 129, 200]
+    for c in range(n_cases):
+        n, l = int(rng.choice(ns)), int(rng.choice(ls))
+        b = int(rng.integers(1, 4))
+        if n * (n - 1) // 2 * l * b > 60_000:
+            b = 1
+        mode = int(rng.integers(3))          # 0: simulated, 1: simulated with gaps, 2: uniformly random residues
+        yield c, CKPTS[c % len(CKPTS)], n, l, b, mode, int(rng.integers(1 << 30))
+
+
+def test_soak_every_accepted_shape_within_the_reference_error(engines, weights):
+    """240 seeded cases over N in 2..40, L in {1, 2, 3, ..., 200}, batches of 1-3, all five checkpoints, simulated /
+    gapped / uniformly random residues: the GPU is within max(1e-4, 2 x |fp32 oracle - fp64 oracle|) of the fp32
+    oracle, finite, and bit-identical one alignment at a time.  0 violations."""
+    bad, worst_default, worst_precise = [], 0.0, 0.0
+    for c, ck, n, l, b, mode, seed in _soak_cases(240, 20261002):
+        if mode == 2:
+            idx = np.random.default_rng(seed).integers(0, 22, (b, n, l)).astype(np.uint8)
+        else:
+            idx = simulate_batch(b, n, l, seed=seed, gaps=(mode == 1))
+        w = weights(ck).tensors
+        e = engines(ck)
+        got = e.forward(idx)
+        f32, f64 = O.forward_batch(w, idx), _f64(w, idx)
+        err = float(np.abs(got - f32).max())
+        bound = max(1e-4, 2.0 * float(np.abs(f32 - f64).max()))
+        selected = l < 16 or n <= 4 or n * (n - 1) // 2 * l < 1024
+        if selected:
+            worst_precise = max(worst_precise, float(np.abs(got - f64).max()))
+        else:
+            worst_default = max(worst_default, err)
+        ok = np.isfinite(got).all() and err <= bound
+        if b > 1:
+            ok = ok and np.array_equal(np.stack([e.forward(x) for x in idx]), got)
+        if not ok:
+            bad.append((c, ck, n, l, b, mode, err, bound))
+    print(f"soak: 240 cases, {len(bad)} violations; default path worst |GPU - fp32 oracle| {worst_default:.3e}, "
+          f"float64 path worst |GPU - fp64 oracle| {worst_precise:.3e}")
+    assert not bad, bad

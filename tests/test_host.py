@@ -109,7 +109,7 @@ def test_abi_symbols_exported(repo):
     build.build()
     lib = engine.load_library()
     header = open(os.path.join(repo, "include/phyloformer_amd.h")).read()
-    declared = set(re.findall(r"^(?:int64_t|uint64_t|int|const char\*)\s+(pf_\w+)\(", header, re.M))
+    declared = set(re.findall(r"^(?:int64_t|uint64_t|int32_t|int|void|const char\*)\s+(pf_\w+)\(", header, re.M))
     assert declared and declared == set(engine.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
