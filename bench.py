@@ -136,17 +136,25 @@ def workload_label(n_seqs, n_sites, ckpt):
     return metric, (f"{tag}: " if tag else "not a BASELINE shape: ") + f"{shape}, {name}"
 
 
-def pmc_traffic(tokens_per_launch):
-    """HBM bytes per k_main launch from the committed PMC passes (profiles/pmc_k_main.json, written by
-    tools/pmc.sh on the GPU box: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units,
-    FETCH_SIZE doubled for 16-byte-per-lane streaming reads as MI355X_MICROARCH.md prescribes),
-    scaled by tokens if the profiled batch differed.  NOT measured by this run.  None if absent."""
+def pmc_traffic(tokens_per_launch, build=None):
+    """(HBM bytes per k_main launch, where the figure comes from).  The bytes are those of the committed PMC passes
+    (profiles/pmc_k_main.json, written by tools/pmc.sh on the GPU box: separate --pmc runs for FETCH_SIZE and
+    WRITE_SIZE, KiB units, FETCH_SIZE doubled for 16-byte-per-lane streaming reads as MI355X_MICROARCH.md
+    prescribes), scaled by tokens if the profiled batch differed - NOT measured by this run, so the file carries the
+    ``kernel_hash`` of the library it was taken with (pf_build_info: k_main's source + the flags of its translation
+    unit) and a library with another hash gets ``None``: stale counters are not reported as this build's."""
     path = os.path.join(REPO, PMC_FILE)
     if not os.path.exists(path):
-        return None
+        return None, f"{PMC_FILE} absent"
     with open(path) as fh:
         p = json.load(fh)
-    return round(p["hbm_bytes_per_token"] * tokens_per_launch)
+    have, want = p.get("kernel_hash"), (build or {}).get("kernel_hash")
+    if want is None or have != want:
+        return None, (f"{PMC_FILE} was taken with kernel_hash {have}, this library has {want}: stale counters are not "
+                      "reported (re-run tools/pmc.sh)")
+    return round(p["hbm_bytes_per_token"] * tokens_per_launch), (
+        f"{PMC_FILE}: separate rocprofv3 --pmc passes of a library with this kernel_hash ({have}; tools/pmc.sh), "
+        "scaled by tokens; not measured by this run")
 
 
 def cpu_baseline(w, shapes=((60, 500), (20, 200)), repeats=3):
@@ -292,16 +300,31 @@ def configs_leg(eng, make_engine_for, device, parity=None):
     return out
 
 
-def beat(stage):
-    """Progress mark for the self-launcher's stall watchdog: one line per stage in $PF_BENCH_PROGRESS/rank<r>."""
+_LAST_TICK = [0.0]
+
+
+def beat(stage, expect_s=None, budget_s=None):
+    """Progress mark for the supervisors' watchdogs: one line per stage in $PF_BENCH_PROGRESS/rank<r>.
+    ``expect_s``: how long the rank expects to stay silent after this mark (a timed region of K asynchronous steps
+    ends in ONE synchronisation: K x the step time measured in the warm-up) - the stall watchdog allows twice that;
+    ``budget_s``: the rank's estimate of the whole run, which stretches the per-rung and overall limits the same way
+    (fixed 75 / 150 / 400 s limits declared a healthy run with many steps stalled)."""
     d = os.environ.get("PF_BENCH_PROGRESS")
     if not d:
         return
+    _LAST_TICK[0] = time.monotonic()
+    extra = (f" expect={expect_s:.1f}" if expect_s is not None else "") + (f" budget={budget_s:.1f}" if budget_s is not None else "")
     try:
         with open(os.path.join(d, "rank" + os.environ.get("RANK", "0")), "a") as fh:
-            fh.write(f"{time.time():.3f} {stage}\n")
+            fh.write(f"{time.time():.3f} {stage.replace(' ', '_')}{extra}\n")
     except OSError:
         pass
+
+
+def tick(stage, expect_s=None):
+    """beat(), at most once a second: for loops."""
+    if time.monotonic() - _LAST_TICK[0] >= 1.0:
+        beat(stage, expect_s)
 
 
 def load_golden(name):
@@ -348,11 +371,11 @@ def parity_case(eng, name, sharded, rank, world, group, copies=2):
     err = float(np.abs(res - ref).max()) if finite else 1e30
     every = group.allgather([err, zlib.crc32(res.tobytes())]) if group is not None else [[err, 0]]
     worst = max(e for e, _ in every)
-    same = len({c for _, c in every}) == 1
+    same = len({c for _, c in every}) == 1 if len(every) > 1 else None
     return {"max_abs_err": worst, "max_abs_ref": round(float(np.abs(ref).max()), 4), "alignments": B,
             "entry_point": "pf_forward_sharded_device" if sharded else "pf_forward_device",
             "sites_per_rank": hi - lo, "collectives": ncoll, "finite": finite, "ranks_bit_identical": same,
-            "ok": bool(worst <= PARITY_BOUND and same)}
+            "ok": bool(worst <= PARITY_BOUND and same is not False)}
 
 
 def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdout, make_engine_for=None):
@@ -379,8 +402,15 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         # One rank per GPU is the contract.  More ranks than devices (`--gpus 8` on a smaller box used to
         # emit a "weak scaling" number measured on shared GPUs) ends the run with its own exit code on EVERY rank -
         # unless --allow-shared-devices, and then the line says what it is: n_gpus = distinct devices, not ranks.
-        seen = group.allgather(device if eng is not None else -1)
-        if any(d < 0 for d in seen) or len(set(seen)) < world:
+        # (identity = the PCI address when the engine has one: with a per-rank HIP_VISIBLE_DEVICES every rank's
+        # ordinal is 0 for a different physical GPU - ADVICE r04)
+        def ident(e, ordinal):
+            try:
+                return list(e.device_pci())
+            except Exception:  # noqa: BLE001 - stand-in engines
+                return ordinal
+        seen = group.allgather(ident(eng, device) if eng is not None else -1)
+        if any(d == -1 for d in seen) or len({json.dumps(d) for d in seen}) < world:
             if not args.allow_shared_devices:
                 if eng is not None:
                     eng.close()
@@ -392,7 +422,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
             if eng is None:
                 device = local_rank % have
                 eng = make_engine(device)
-            n_devices = len(set(group.allgather(device)))
+            n_devices = len({json.dumps(d) for d in group.allgather(ident(eng, device))})
             comm_note = (f"{world} ranks share {n_devices} device(s) (--allow-shared-devices): NOT a scaling result; "
                          "RCCL refuses two ranks on one device, so whole alignments are sharded")
             if rank == 0:
@@ -463,12 +493,17 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         if group is not None:
             group.barrier()
 
-    def timed(fn, steps):
+    est = {"step": None}          # seconds per step, measured in the warm-up (None: no warm-up)
+
+    def timed(fn, steps, stage="timed region", scale=1.0):
+        expect = est["step"] * steps * scale if est["step"] else None
+        beat(stage + " begins", expect)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
-        barrier()
+            tick(stage, expect)      # (launches are asynchronous: the loop runs ahead of the GPU, the region ends in
+        barrier()                    #  one synchronisation - hence the expectation published above)
         dt = time.perf_counter() - t0
         return group.allreduce_max(dt) if group is not None else dt
 
@@ -479,10 +514,23 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         eng.set_option("overlap", 1 if two else 0)
 
     streams(not args.one_stream)
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    beat("warm-up")
+    t_w = time.perf_counter()
+    if args.warmup:
+        step()                       # first touch: workspaces, communicator channels
+        eng.synchronize()
+        beat("first step")
+        if args.warmup > 1:
+            t_w = time.perf_counter()
+        for _ in range(args.warmup - 1):
+            step()
+            tick("warm-up")
+        eng.synchronize()
+    if args.warmup:
+        est["step"] = (time.perf_counter() - t_w) / max(1, args.warmup - 1)
+        # three regions of `steps` (two-stream, one-stream, host buffers) + parity / configs / baseline allowance
+        beat("warm-up", budget_s=est["step"] * args.steps * 3.5 + 60.0)
+    else:
+        beat("warm-up")
     sampler = None
     if rank == 0 and not args.no_power:
         try:
@@ -505,7 +553,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
         step()
         eng.set_option("profile", 2)   # HIP events around every k_main launch only (see header)
         eng.profile_reset()
-        dt_one = timed(step, args.steps)
+        dt_one = timed(step, args.steps, "roofline region", 1.2)
         prof["main"] = eng.profile_get("main")
         eng.set_option("profile", 0)
         streams(not args.one_stream)
@@ -515,7 +563,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
     assert np.isfinite(result).all() and (result > 0).all()
     # the same step with host buffers: H2D + forward + D2H + synchronisation per call
     step_host()
-    dt_host = timed(step_host, args.steps)
+    dt_host = timed(step_host, args.steps, "host-buffer region", 1.2)
     if sampler:
         sampler.__exit__(None, None, None)
     info = eng.device_info()
@@ -566,7 +614,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
 
         step3()
         steps3 = max(2, min(args.steps, 5))
-        dt3 = timed(step3, steps3)
+        dt3 = timed(step3, steps3, "configs[3] region")
         eng.free(d3)
         eng.free(o3)
         tot3 = (b3 if sharded else b3 * world) * steps3
@@ -578,21 +626,67 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
             "frac_mfma_per_gpu": round(FLOPS_ALG_PER_TOKEN * tok3 / (dt3 / steps3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
             "max_abs_err": (parity or {}).get("configs[3] 60x2000", {}).get("max_abs_err")}}
         beat("configs[3]")
+        if sharded:
+            # The case site sharding exists for: ONE long alignment per step, latency and rate.
+            # With a single alignment there is no second half-batch to hide the collectives under: the 7 all-reduces
+            # of [P][72] floats (510 KB) sit on the critical path - every kernel behind them (k_rowfin -> k_colstats ->
+            # k_main) needs the reduced statistics of ALL pairs, so a split of the pairs would overlap nothing but the
+            # 5 us k_rowfin.  Reported as measured: ms per alignment, and beside it the same
+            # alignment unsharded on this rank's GPU for the ratio.
+            one = np.ascontiguousarray(simulate_batch(1, n3, l3, seed=5)[:, :, lo3:hi3])
+            d1, o1 = eng.malloc(max(one.nbytes, 1)), eng.malloc(p3 * 4)
+            eng.h2d(d1, one)
+
+            def step1():
+                eng.forward_sharded_device(d1, 1, n3, lo3, hi3, l3, o1)
+
+            step1()
+            c0 = eng.collective_count()
+            steps1 = max(3, min(args.steps, 10))
+            dt1 = timed(step1, steps1, "strong-scaling region")
+            ncoll1 = (eng.collective_count() - c0) / steps1
+            res1 = np.empty((1, p3), np.float32)
+            eng.d2h(res1, o1)
+            crcs = group.allgather(zlib.crc32(res1.tobytes())) if group is not None else [0]
+            entry = {"n_seqs": n3, "n_sites": l3, "global_batch": 1, "sites_per_rank": hi3 - lo3, "timed_steps": steps1,
+                     "ms_per_alignment": round(dt1 / steps1 * 1e3, 4), "alignments_per_s": round(steps1 / dt1, 3),
+                     "collectives_per_alignment": round(ncoll1, 2), "scaling": "strong",
+                     "ranks_bit_identical": (len(set(crcs)) == 1) if world > 1 else None, "finite": bool(np.isfinite(res1).all())}
+            if world == 1:
+                # single rank (--force-dist): the same alignment through the unsharded entry point - the same bits,
+                # and the cost of the seven (single-rank) collectives and their k_rowsum launches
+                full = np.ascontiguousarray(simulate_batch(1, n3, l3, seed=5))
+                eng.h2d(d1, full)
+                ou = eng.malloc(p3 * 4)
+                eng.forward_device(d1, 1, n3, l3, ou)
+                dtu = timed(lambda: eng.forward_device(d1, 1, n3, l3, ou), steps1, "strong-scaling reference")
+                resu = np.empty((1, p3), np.float32)
+                eng.d2h(resu, ou)
+                eng.free(ou)
+                entry["bit_identical_to_pf_forward"] = bool(np.array_equal(resu, res1))
+                entry["ms_per_alignment_unsharded"] = round(dtu / steps1 * 1e3, 4)
+            eng.free(d1)
+            eng.free(o1)
+            extra_configs[f"60x2000 x1 sites-sharded x{world}"] = entry
+            beat("strong scaling")
     if rank == 0:
         tokens_per_launch = B * P * (hi - lo)
         roof = None
+        try:
+            build = eng.build_info()
+        except Exception:  # noqa: BLE001 - stand-in engines have no native library
+            build = None
         if prof.get("main", (0, 0))[0]:
             n_main, ms_main = prof["main"]
             avg_s = ms_main / n_main * 1e-3
             nb = weights.n_blocks
             flops = tokens_per_launch * ((nb - 1) * FLOPS_MAIN_MID + FLOPS_MAIN_LAST) / nb
             ach = flops / avg_s / 1e12
+            traffic, traffic_source = pmc_traffic(tokens_per_launch, build)
             roof = {"bound": "mfma", "kernel": "k_main", "achieved": round(ach, 2),
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(tokens_per_launch),
-                    "traffic_source": f"{PMC_FILE}: separate rocprofv3 --pmc passes of this build (tools/pmc.sh), "
-                                      "scaled by tokens; not measured by this run",
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_main,
                     "schedule": "second timed region of the same steps with the batch on one stream (a launch covers "
                                 "the whole batch and has the chip to itself); `value` is the default two-stream schedule"
@@ -615,7 +709,11 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
                        "collectives_per_step": round(collectives_per_step, 2),
                        "reserve_cus": args.reserve_cus if comm else None,
                        "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if comm else None,
-                       "rung": rung_info()},
+                       "rung": rung_info(),
+                       # what the timed library was built from (pf_build_info): compiler, the scheduling strategy that
+                       # REALLY compiled the kernels (sched_fallback: true = hipcc could not use the intended one),
+                       # hashes of the sources
+                       "build": build},
             "value_definition": "indices resident in HBM when the timed region starts (task statement, "
                                 "Measurement: the PCIe-inclusive rate is never `value`); value_pcie_inclusive is "
                                 "the rate SURVEY.md 8d words its metric on",
@@ -649,7 +747,8 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
             errs = [c["max_abs_err"] for c in parity.values()]
             line["max_abs_err"] = max(errs) if errs else None
             line["max_abs_err_ok"] = bool(errs) and all(c["ok"] for c in parity.values())
-            line["ranks_bit_identical"] = all(c["ranks_bit_identical"] for c in parity.values())
+            # (one rank: there is nothing to compare - null, not a vacuous true)
+            line["ranks_bit_identical"] = all(c["ranks_bit_identical"] for c in parity.values()) if world > 1 else None
             line["parity"] = {"bound": PARITY_BOUND, "cases": parity,
                               "reference": "outputs of the reference's CPU forward committed under tests/golden/ "
                                            "(oracle/gen_golden.py; data, not the oracle)",
@@ -723,16 +822,39 @@ def self_launch(args, argv):
                 "PF_RUN_ID": uuid.uuid4().hex, "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     for k in ("PF_BENCH_RUNG", "PF_BENCH_RUNG_NAME", "PF_BENCH_RUNG_HISTORY", "PF_BENCH_PROGRESS"):
         env.pop(k, None)
+    # supervisor 0 stretches the limits when the ranks publish a longer expected duration (many steps): it writes
+    # the new overall limit (seconds since the start) here, and this process follows it
+    fd, limit_file = tempfile.mkstemp(prefix="pf_bench_limit_")
+    os.close(fd)
+    env["PF_BENCH_LIMIT_FILE"] = limit_file
+    t_start = time.monotonic()
     procs = []
     for r in range(world):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
                                       env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), start_new_session=True,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    deadline = time.monotonic() + args.launch_timeout + 45.0
-    while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
+    limit = args.launch_timeout
+
+    def current_limit():
+        try:
+            with open(limit_file) as fh:
+                return max(args.launch_timeout, float(fh.read().strip() or 0))
+        except (OSError, ValueError):
+            return args.launch_timeout
+    while any(p.poll() is None for p in procs):
+        limit = current_limit()
+        if time.monotonic() - t_start > limit + 45.0:
+            break
         time.sleep(0.05)
+    try:
+        os.unlink(limit_file)
+    except OSError:
+        pass
     late = [p for p in procs if p.poll() is None]
-    for p in late:                      # exactly the process groups started above (a supervisor and its rank)
+    # Every process group started above is signalled, the late ones and those whose supervisor has already left: a
+    # supervisor that died on an exception may have left its rank behind, parked in a collective and holding its GPU
+    # (ADVICE r04).  The groups are this launcher's own (start_new_session): nothing else can be in them.
+    for p in procs:
         try:
             os.killpg(p.pid, 15)
         except OSError:
@@ -747,7 +869,7 @@ def self_launch(args, argv):
                 pass
             p.wait()
     if late:
-        print(f"bench: watchdog: {len(late)} supervisor(s) still running {args.launch_timeout + 45:.0f} s after the start; "
+        print(f"bench: watchdog: {len(late)} supervisor(s) still running {limit + 45:.0f} s after the start; "
               "killed", file=sys.stderr)
         return EXIT_WATCHDOG
     codes = [p.returncode for p in procs]
@@ -766,16 +888,59 @@ def supervise(args, argv, rank, world):
     stalled rank anywhere makes every supervisor kill its child and start a fresh one for the next rung, under a new
     rendezvous key.  Supervisor 0 relays its child's JSON line.  Exit code: 0, or 3 / 4 from the ranks (parity bound,
     too few GPUs: final), 124 if every rung was abandoned by a watchdog, else 1."""
+    import signal
     from phyloformer_amd.rendezvous import TcpGroup, default_key
+
+    class Stopped(Exception):
+        pass
+
+    def on_signal(signum, _frame):      # torchrun and self_launch stop workers with SIGTERM: unwind through the finally
+        raise Stopped(signum)           # blocks below, so that the rank this supervisor started never outlives it
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, on_signal)
+        except (ValueError, OSError):   # not the main thread (tests)
+            pass
+
+    def stop_child(child):
+        if child is not None and child.poll() is None:            # exactly the process started below
+            child.terminate()
+            try:
+                child.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.wait()
+
+    def last_mark(path):
+        """(stage, expect_s, budget_s) of the rank's newest progress line."""
+        stage, expect, budget = "-", 0.0, 0.0
+        try:
+            with open(path) as fh:
+                lines = fh.read().strip().splitlines()
+        except OSError:
+            return stage, expect, budget
+        for ln in lines:
+            for tok in ln.split()[2:]:
+                if tok.startswith("budget="):
+                    budget = float(tok[7:])
+        if lines:
+            parts = lines[-1].split()
+            stage = parts[1] if len(parts) > 1 else "-"
+            for tok in parts[2:]:
+                if tok.startswith("expect="):
+                    expect = float(tok[7:])
+        return stage, expect, budget
     base_run = os.environ.get("PF_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID", "none")
     sup = TcpGroup(rank, world, key=default_key() + "_supervisors", timeout=max(30.0, args.rung_timeout))
     t_launch = time.monotonic()
     history, rc, text = [], 1, ""
     rungs = ladder(args)
     first = len(RUNGS) - len(rungs) + 1
+    child = None
+    launch_limit = args.launch_timeout
     try:
         for index, (name, extra) in enumerate(rungs, start=first):
-            left = args.launch_timeout - (time.monotonic() - t_launch)
+            left = launch_limit - (time.monotonic() - t_launch)
             if any(sup.allgather(index > first and left < 15)):
                 if rank == 0:
                     print("bench: no time left for another rung", file=sys.stderr)
@@ -802,16 +967,24 @@ def supervise(args, argv, rank, world):
                 now = time.monotonic()
                 if sz != size:
                     size, last = sz, now
-                stage = "-"
-                try:
-                    with open(mark) as fh:
-                        stage = (fh.read().strip().splitlines() or ["- -"])[-1].split(" ", 1)[-1]
-                except OSError:
-                    pass
+                stage, expect, budget = last_mark(mark)
                 seen = sup.allgather([child.poll(), round(now - last, 2), round(now - t0, 2),
-                                      round(now - t_launch, 2), stage])
+                                      round(now - t_launch, 2), stage, expect, budget])
                 codes = [c for c, *_ in seen]
-                where = "; ".join(f"rank {r}: {st}" for r, (*_x, st) in enumerate(seen))
+                where = "; ".join(f"rank {r}: {st}" for r, (_c, _a, _b, _d, st, *_x) in enumerate(seen))
+                # limits stretch with what the ranks expect (functions of the exchanged values: the same everywhere)
+                stall_limit = max(args.stall_timeout, 2.0 * max(e for *_x, e, _b in seen) + 30.0)
+                rung_limit = max(args.rung_timeout, 2.0 * max(b for *_x, b in seen) + 60.0)
+                new_launch = launch_limit if rung_limit <= args.rung_timeout else \
+                    max(launch_limit, seen[0][3] - seen[0][2] + rung_limit + 30.0)     # only a published budget stretches
+                if new_launch > launch_limit:
+                    launch_limit = new_launch
+                    if rank == 0 and os.environ.get("PF_BENCH_LIMIT_FILE"):
+                        try:
+                            with open(os.environ["PF_BENCH_LIMIT_FILE"], "w") as fh:
+                                fh.write(f"{launch_limit:.1f}")
+                        except OSError:
+                            pass
                 if any(c not in (None, 0) for c in codes):
                     bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
                     rc = bad[0][1] if all(c == bad[0][1] for _, c in bad) and bad[0][1] in (EXIT_PARITY, EXIT_DEVICES) else 1
@@ -821,20 +994,14 @@ def supervise(args, argv, rank, world):
                     break
                 if all(c == 0 for c in codes):
                     break
-                if seen[0][2] > args.rung_timeout or seen[0][3] > args.launch_timeout:
+                if seen[0][2] > rung_limit or seen[0][3] > launch_limit:
                     rc, why = EXIT_WATCHDOG, f"watchdog: ranks still running after {seen[0][2]:.0f} s ({where})"
                     break
-                if min(age for _c, age, *_ in seen) > args.stall_timeout:
-                    rc, why = EXIT_WATCHDOG, f"watchdog: no progress from any rank for {args.stall_timeout:.0f} s ({where})"
+                if min(age for _c, age, *_ in seen) > stall_limit:
+                    rc, why = EXIT_WATCHDOG, f"watchdog: no progress from any rank for {stall_limit:.0f} s ({where})"
                     break
                 time.sleep(0.25)
-            if child.poll() is None:            # exactly the process started above
-                child.terminate()
-                try:
-                    child.wait(timeout=5)
-                except subprocess.TimeoutExpired:
-                    child.kill()
-                    child.wait()
+            stop_child(child)
             if reader is not None:
                 reader.join(timeout=5)
             shutil.rmtree(progress, ignore_errors=True)
@@ -849,7 +1016,13 @@ def supervise(args, argv, rank, world):
                 break
             history.append({"rung": index, "name": name, "why": why})
             text = ""
+    except Stopped as exc:
+        print(f"bench: supervisor {rank}: signal {exc.args[0]}; stopping its rank", file=sys.stderr)
+        rc, text = 128 + int(exc.args[0]), ""
     finally:
+        # whatever way this function is left - a peer supervisor gone (allgather raises), a signal, a bug - the rank
+        # it started does not outlive it (an orphan would sit in an RCCL collective holding its GPU)
+        stop_child(child)
         sup.close()
     if rank == 0 and text:
         sys.stdout.write(text)

@@ -122,7 +122,7 @@ def main(argv=None):
         return run_site_sharded(args, paths, rank, world, out_dir, tqdm)
 
     t0 = time.perf_counter()
-    model = Phyloformer.from_checkpoint(args.weights, device=args.device)
+    model = Phyloformer.from_checkpoint(args.weights, device=args.device, engine_factory=scheduler.cli_engine)
     model.eval()
     load_s = time.perf_counter() - t0
 

@@ -186,6 +186,11 @@ class Engine:
         self._check(self._lib.pf_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)))
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
+    def build_info(self) -> Dict[str, object]:
+        """What the library behind this engine was built from (``pf_build_info``)."""
+        import json
+        return json.loads(self._lib.pf_build_info().decode())
+
     def device_pci(self) -> Tuple[int, int, int]:
         """(domain, bus, device) of this engine's GPU - the key rocm_smi finds it by (phyloformer_amd/smi.py)."""
         d, b, v = C.c_int32(), C.c_int32(), C.c_int32()

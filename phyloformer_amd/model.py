@@ -21,18 +21,21 @@ MAX_SEQS = 200  # SEQ2PAIR = seq2pair(200), model.py:39
 class Phyloformer:
     """``Phyloformer(...)`` + ``load_state_dict`` + ``.to(device)`` + ``.eval()`` in one object."""
 
-    def __init__(self, weights: Optional[ModelWeights] = None, device: int = 0, **_ignored):
+    def __init__(self, weights: Optional[ModelWeights] = None, device: int = 0, engine_factory=None, **_ignored):
         # The reference constructor swallows unknown keyword arguments (model.py:122);
         # checkpoint hyper-parameters are read from the tensors instead.
+        # engine_factory(weights, device): the engine to bind - ``Engine`` unless a caller passes another one
+        # explicitly (infer_alns.py hands its test hook through here; the library API never reads the environment)
         self.device = device
+        self._engine_factory = engine_factory or Engine
         self.weights: Optional[ModelWeights] = None
         self.engine: Optional[Engine] = None
         if weights is not None:
             self._bind(weights)
 
     @classmethod
-    def from_checkpoint(cls, path, device: int = 0) -> "Phyloformer":
-        return cls(load_weights(path), device=device)
+    def from_checkpoint(cls, path, device: int = 0, engine_factory=None) -> "Phyloformer":
+        return cls(load_weights(path), device=device, engine_factory=engine_factory)
 
     def load_state_dict(self, state_dict: Dict[str, np.ndarray], strict: bool = False):
         """Accepts the prefix-stripped dict of infer_alns.py:75-82 (numpy arrays or tensors)."""
@@ -45,8 +48,7 @@ class Phyloformer:
         if self.engine is not None:
             self.engine.close()
         self.weights = weights
-        from .scheduler import cli_engine          # Engine(weights, device) unless a test names a stand-in
-        self.engine = cli_engine(weights, self.device)
+        self.engine = self._engine_factory(weights, self.device)
 
     def eval(self):
         return self

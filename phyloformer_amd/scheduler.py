@@ -443,12 +443,57 @@ def run_multi_device(script: str, argv: List[str], devices: Sequence[int], shard
             cmd += ["--shard", "sites"]
         procs.append(subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True,
                                       env=dict(env, RANK=str(r), LOCAL_RANK=str(r)) if shard == "sites" else None))
+    # One reader thread per child keeps its stderr drained (a rank blocked on a full 64 KB pipe while its peers wait
+    # for it in a collective is a deadlock), the parent polls all children: in sites mode the ranks depend on each
+    # other, so as soon as one exits non-zero - or no child has produced a line or exited for `stall_s` - the others,
+    # parked in an all-reduce that will never complete, are terminated.
+    lines: List[List[str]] = [[] for _ in procs]
+    last_event = [time.monotonic()]
+
+    def drain(k, pipe):
+        for line in pipe:
+            lines[k].append(line)
+            last_event[0] = time.monotonic()
+        pipe.close()
+    readers = [threading.Thread(target=drain, args=(k, p.stderr), daemon=True) for k, p in enumerate(procs)]
+    for t in readers:
+        t.start()
+    stall_s = float(os.environ.get("PF_CLI_STALL_TIMEOUT", "900"))
+    failed, alive = None, set(range(len(procs)))
+    while alive:
+        for k in sorted(alive):
+            code = procs[k].poll()
+            if code is not None:
+                alive.discard(k)
+                last_event[0] = time.monotonic()
+                if code != 0 and failed is None:
+                    failed = (k, code)
+        stalled = shard == "sites" and time.monotonic() - last_event[0] > stall_s
+        if alive and shard == "sites" and (failed is not None or stalled):
+            why = (f"rank {failed[0]} exited with code {failed[1]}" if failed is not None
+                   else f"no rank made progress for {stall_s:.0f} s")
+            print(f"infer_alns: {why}; terminating the other site-sharded ranks", file=sys.stderr)
+            for k in alive:
+                procs[k].terminate()
+            deadline = time.monotonic() + 10
+            for k in list(alive):
+                try:
+                    procs[k].wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    procs[k].kill()
+                    procs[k].wait()
+            if failed is None:
+                failed = (-1, 124)
+            alive.clear()
+        if alive:
+            time.sleep(0.05)
+    for t in readers:
+        t.join(timeout=5)
     rc, reports = 0, []
-    for p in procs:
-        _out, err = p.communicate()
-        rc = rc or p.returncode
+    for k, p in enumerate(procs):
+        rc = rc or (p.returncode if p.returncode is not None else 1)
         rep = None
-        for line in (err or "").splitlines():
+        for line in "".join(lines[k]).splitlines():
             if line.startswith("{") and '"alignments"' in line:
                 try:
                     rep = json.loads(line)
@@ -459,4 +504,6 @@ def run_multi_device(script: str, argv: List[str], devices: Sequence[int], shard
                 print(line, file=sys.stderr)
         if rep is not None:
             reports.append(rep)
+    if failed is not None and rc == 0:
+        rc = failed[1] or 1
     return rc, reports

@@ -126,3 +126,31 @@ def make_failing_until_rung3(device):
     if rung == "2" and os.environ.get("RANK") == "1":
         os._exit(9)
     return make_hanging_on_rung1(device)
+
+
+def make_slow(device):
+    """A healthy but slow GPU: launches return at once, every synchronisation then takes 0.15 s per step queued since
+    the last one - a timed region of K steps is ONE long silence, as on the real engine."""
+    import time
+    eng = make_for_bench(device)
+    queued = [0]
+    fs, fp, sync = eng.forward_sharded_device, eng.forward_device, eng.synchronize
+
+    def fsd(*a, **k):
+        queued[0] += 1
+        return fs(*a, **k)
+
+    def fd(*a, **k):
+        queued[0] += 1
+        return fp(*a, **k)
+
+    def synchronize():
+        time.sleep(0.15 * queued[0])
+        queued[0] = 0
+        return sync()
+
+    def d2h(out, d, _orig=eng.d2h):
+        synchronize()
+        return _orig(out, d)
+    eng.forward_sharded_device, eng.forward_device, eng.synchronize, eng.d2h = fsd, fd, synchronize, d2h
+    return eng

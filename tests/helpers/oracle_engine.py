@@ -39,7 +39,8 @@ class OracleEngine:
             # (a peer that failed before this point never joins: with the injected failure the others give up fast,
             # the way a real ncclCommInitRank reports a bootstrap error on every rank)
             self.comm = TcpGroup(rank, world, key="oracle_comm_" + bytes(uid)[:16].hex(),
-                                 timeout=4 if os.environ.get("PF_FAKE_FAIL_COMM_ON") else 60)
+                                 timeout=4 if os.environ.get("PF_FAKE_FAIL_COMM_ON") else
+                                 600 if os.environ.get("PF_FAKE_DIE_RANK") else 60)
 
     def comm_destroy(self):
         self.close()
@@ -66,6 +67,8 @@ class OracleEngine:
         return out[0] if one else out
 
     def forward_sharded(self, idx_local, lo, hi, L):
+        if os.environ.get("PF_FAKE_DIE_RANK") == str(self.rank) and self.ncoll > 0:
+            os._exit(7)                              # a rank lost mid-run (OOM kill, HIP error): its peers wait in a collective
         idx_local = np.asarray(idx_local, np.uint8)
         assert idx_local.shape[-1] == hi - lo
         return np.stack([O.forward_rank(self.w, a, L, self._allreduce) for a in idx_local])

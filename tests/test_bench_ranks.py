@@ -58,7 +58,9 @@ def test_bench_rank_logic_world2(fail_comm_on, tmp_path):
             gold = [e for e in res[rank][0] if e[0] == "sharded" and e[2] == 60]
             assert gold[0] == ("sharded", 2, 60, 250 * rank, 250 * (rank + 1), 500)
             assert gold[1] == ("sharded", 2, 60, 1000 * rank, 1000 * (rank + 1), 2000)
-            assert gold[2:] == [("sharded", 2, 60, 1000 * rank, 1000 * (rank + 1), 2000)] * 4
+            assert gold[2:6] == [("sharded", 2, 60, 1000 * rank, 1000 * (rank + 1), 2000)] * 4
+            # the strong-scaling case: ONE 60 x 2000 alignment per step, warm-up + 3 timed steps
+            assert gold[6:] == [("sharded", 1, 60, 1000 * rank, 1000 * (rank + 1), 2000)] * 4
             opts = [e[1:] for e in res[rank][0] if e[0] == "opt" and e[1] in ("two_streams", "overlap")]
             assert opts == [("two_streams", 1), ("overlap", 1), ("two_streams", 0), ("overlap", 0),
                             ("two_streams", 1), ("overlap", 1)]
@@ -67,6 +69,9 @@ def test_bench_rank_logic_world2(fail_comm_on, tmp_path):
         assert line["config"]["rccl"]["library"].endswith("librccl.so.1")
         c3 = line["configs"]["configs[3] 60x2000 sites-sharded x2"]
         assert c3["sites_per_rank"] == 1000 and c3["global_batch"] == 2 and c3["alignments_per_s"] > 0 and c3["max_abs_err"] == 0.0
+        one = line["configs"]["60x2000 x1 sites-sharded x2"]
+        assert one["global_batch"] == 1 and one["scaling"] == "strong" and one["sites_per_rank"] == 1000
+        assert one["ms_per_alignment"] > 0 and one["ranks_bit_identical"] is True and one["timed_steps"] == 3
         cases = line["parity"]["cases"]
         assert set(cases) == {"configs[2] 60x500", "configs[3] 60x2000"}
         assert all(c["entry_point"] == "pf_forward_sharded_device" and c["collectives"] == 14 and c["ok"] for c in cases.values())
@@ -143,6 +148,59 @@ def test_bench_self_launch_watchdog(tmp_path):
                       "--no-power", "--launch-timeout", "3"],
                      {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_hanging", "TMPDIR": str(tmp_path)})
     assert res.returncode == 124 and "watchdog" in res.stderr
+
+
+def test_slow_but_progressing_ranks_are_not_abandoned(tmp_path):
+    """the limits of the ladder were fixed (75 / 150 / 400 s) whatever --steps is, and a timed region of K
+    asynchronous steps ends in ONE synchronisation - one long silence.  The ranks now publish, from the step time
+    measured in the warm-up, how long the next region and the whole run should take; the supervisors stretch the
+    stall / rung / overall limits to twice that.  Here a step takes 0.15 s and a region of 40 steps 6 s against
+    --stall-timeout 2 / --rung-timeout 10 / --launch-timeout 20: the run must finish on rung 1, not be declared
+    stalled."""
+    res = _run_bench(["--gpus", "2", "--steps", "40", "--warmup", "3", "--batch", "2", "--n-seqs", "6", "--n-sites", "45",
+                      "--no-power", "--no-parity", "--no-configs", "--stall-timeout", "2", "--rung-timeout", "10",
+                      "--launch-timeout", "20"],
+                     {"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_slow", "TMPDIR": str(tmp_path)}, timeout=200)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert line["config"]["rung"]["index"] == 1 and line["config"]["rung"]["abandoned"] == []
+    assert line["steps"] == 40 and line["ms_per_step"] > 100
+
+
+def test_a_stopped_supervisor_takes_its_rank_with_it(tmp_path):
+    """torchrun stops its workers with SIGTERM; a supervisor that just died used to leave the rank it had
+    started behind - parked in a collective, holding its GPU.  Two supervisors in the external-launcher form, ranks
+    that hang; SIGTERM to the supervisors: their children are gone within seconds."""
+    import signal
+    import subprocess
+    import time
+    import psutil
+    sys.path.insert(0, REPO)
+    import bench
+    port = str(bench.free_port())
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update({"PF_BENCH_ENGINE_FACTORY": "helpers.fake_engine:make_hanging", "TMPDIR": str(tmp_path), "WORLD_SIZE": "2",
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "PF_RUN_ID": uuid.uuid4().hex,
+                "PYTHONPATH": os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), REPO])})
+    sups = [subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                              "--no-power"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, text=True) for r in range(2)]
+    try:
+        kids, t0 = [], time.time()
+        while len(kids) < 2 and time.time() - t0 < 60:
+            kids = [c for p in sups for c in psutil.Process(p.pid).children()]
+            time.sleep(0.2)
+        assert len(kids) == 2, "both supervisors start a rank"
+        for p in sups:
+            p.send_signal(signal.SIGTERM)
+        for p in sups:
+            assert p.wait(timeout=30) == 128 + signal.SIGTERM
+        gone, alive = psutil.wait_procs(kids, timeout=15)
+        assert not alive, alive
+    finally:
+        for p in sups:
+            if p.poll() is None:
+                p.kill()
 
 
 def test_workload_label_follows_the_shape():

@@ -256,3 +256,18 @@ def test_cli_site_sharded_falls_back_to_files_when_a_communicator_fails(small_di
     assert plain.returncode == 0
     for n in sorted(os.listdir(tmp_path / "plain")):
         assert (tmp_path / "fb" / n).read_bytes() == (tmp_path / "plain" / n).read_bytes(), n
+
+
+def test_cli_site_sharded_dead_rank_ends_the_run_instead_of_hanging(small_dir, tmp_path):
+    """in sites mode the ranks depend on each other.  Rank 1 dies after its first launch (injected
+    os._exit); rank 0 is then parked in a collective that can never complete (the stand-in's own timeout is 600 s).
+    The launcher polls all children, terminates the survivors and returns non-zero within seconds."""
+    import time
+    env = {"PF_CLI_ENGINE_FACTORY": "helpers.oracle_engine:make", "PF_FAKE_DIE_RANK": "1", "TMPDIR": str(tmp_path)}
+    ckpt = os.path.join(REPO, "models", "pf_base.ckpt")
+    t0 = time.time()
+    r = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "dead"), "--devices", "0,1", "--shard", "sites", "--batch", "1"], env,
+             timeout=200)
+    assert r.returncode != 0
+    assert "rank 1 exited with code 7; terminating the other site-sharded ranks" in r.stderr
+    assert time.time() - t0 < 120
