@@ -261,12 +261,16 @@ int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, i
  *   PF_FASTA_EEMPTY    no record at all (RuntimeError from one_hot in the reference; so is N records of
  *                      length 0, which returns PF_OK with *l_out = 0)
  *   PF_FASTA_ECAP      idx_cap or max_seqs too small
+ *   PF_FASTA_EUTF8     a header that bytes.decode("utf8") refuses, *detail = offset of the id in `data`
+ *                      (UnicodeDecodeError at that line, data.py:22)
+ * Errors are reported in file order: the first offending line decides, as in the reference's loop.
  */
 #define PF_FASTA_EBYTE (-16)
 #define PF_FASTA_ERAGGED (-17)
 #define PF_FASTA_ENOHEADER (-18)
 #define PF_FASTA_EEMPTY (-19)
 #define PF_FASTA_ECAP (-20)
+#define PF_FASTA_EUTF8 (-21)
 int pf_parse_fasta(const char* data, int64_t len, uint8_t* idx, int64_t idx_cap, int64_t* id_spans,
                    int32_t max_seqs, int32_t* n_out, int32_t* l_out, int64_t* detail);
 

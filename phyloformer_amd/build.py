@@ -42,10 +42,10 @@ UNITS: Dict[str, List[str]] = {
     "pf_precise.hip": [f"--offload-arch={ARCH}"],
     "pf_hostio.cpp": [],
 }
-HEADERS = ["pf_device.hip.h", "pf_mha.hip.h", "pf_precise.hip.h", "pf_precise_host.hip.h"]
+HEADERS = ["pf_device.hip.h", "pf_mha.hip.h", "pf_precise.hip.h", "pf_precise_host.hip.h", "pf_layout.h", "pf_host_prep.h"]
 # what decides the bits and the speed of the dominant kernels (k_main, k_colstats): the PMC traffic file under
 # profiles/ is tied to this hash (bench.py: a mismatch means the counters are stale -> traffic null)
-KERNEL_FILES = ["pf_device.hip.h"]
+KERNEL_FILES = ["pf_device.hip.h", "pf_layout.h"]
 
 
 def hipcc_path() -> str:

@@ -84,6 +84,33 @@ inline int format_f10(float x, char* out) {
 // bytes.strip() of CPython: space, \t, \n, \r, \x0b, \x0c
 inline bool is_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
 
+// Would bytes.decode("utf8") accept [p, p + n)?  (CPython's strict decoder: no overlong forms, no surrogates,
+// nothing above U+10FFFF.)  The reference decodes every header where it meets it (data.py:22).
+inline bool valid_utf8(const unsigned char* p, int64_t n) {
+    int64_t i = 0;
+    while (i < n) {
+        const unsigned char c = p[i];
+        if (c < 0x80) { ++i; continue; }
+        int extra;
+        unsigned char lo = 0x80, hi = 0xBF;
+        if (c >= 0xC2 && c <= 0xDF) extra = 1;
+        else if (c == 0xE0) { extra = 2; lo = 0xA0; }
+        else if (c >= 0xE1 && c <= 0xEC) extra = 2;
+        else if (c == 0xED) { extra = 2; hi = 0x9F; }
+        else if (c >= 0xEE && c <= 0xEF) extra = 2;
+        else if (c == 0xF0) { extra = 3; lo = 0x90; }
+        else if (c >= 0xF1 && c <= 0xF3) extra = 3;
+        else if (c == 0xF4) { extra = 3; hi = 0x8F; }
+        else return false;
+        if (i + extra >= n) return false;                  // truncated sequence
+        if (p[i + 1] < lo || p[i + 1] > hi) return false;
+        for (int k = 2; k <= extra; ++k)
+            if (p[i + k] < 0x80 || p[i + k] > 0xBF) return false;
+        i += extra + 1;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,6 +139,11 @@ int pf_parse_fasta(const char* data, int64_t len, uint8_t* idx, int64_t idx_cap,
                 if (n > 0) {
                     if (first_len < 0) first_len = cur_len;
                     else if (cur_len != first_len) ragged = true;
+                }
+                if (!valid_utf8((const unsigned char*)data + a + 1, b - (a + 1))) {
+                    *detail = a + 1;                     // offset of the id: the caller decodes it to raise
+                    *n_out = n;
+                    return PF_FASTA_EUTF8;
                 }
                 if (id_spans) {
                     if (n >= max_seqs) return PF_FASTA_ECAP;
@@ -162,7 +194,8 @@ static int64_t format_phylip_impl(const float* preds, int32_t n, const char* con
     auto at = [&](int64_t i, int64_t j) -> float {
         if (i == j) return 0.0f;
         if (i > j) { int64_t t = i; i = j; j = t; }
-        return preds[i * n - i * (i + 1) / 2 + (j - i - 1)];
+        // dm + dm.T of the reference (infer_alns.py:19-20) adds the zero of the other triangle: -0.0 becomes 0.0
+        return preds[i * n - i * (i + 1) / 2 + (j - i - 1)] + 0.0f;
     };
     for (int32_t i = 0; i < n; ++i) {
         const char* id = ids[i] ? ids[i] : "";

@@ -16,14 +16,25 @@ import numpy as np
 
 from .engine import load_library
 
-PF_FASTA_EBYTE, PF_FASTA_ERAGGED, PF_FASTA_ENOHEADER, PF_FASTA_EEMPTY, PF_FASTA_ECAP = -16, -17, -18, -19, -20
+PF_FASTA_EBYTE, PF_FASTA_ERAGGED, PF_FASTA_ENOHEADER, PF_FASTA_EEMPTY, PF_FASTA_ECAP, PF_FASTA_EUTF8 = -16, -17, -18, -19, -20, -21
 
 
 PF_EIO = -6
 
 
-def parse_error(rc: int, l: int, detail: int, path: str = "") -> "BaseException | None":
+def parse_error(rc: int, l: int, detail: int, path: str = "", data: bytes = b"") -> "BaseException | None":
     """The exception the reference raises where pf_parse_fasta returns ``rc`` (None = a valid alignment)."""
+    if rc == PF_FASTA_EUTF8:
+        # the header at offset `detail` is not UTF-8: let bytes.decode build the reference's exception (data.py:22)
+        if not data and path:
+            with open(path, "rb") as fh:
+                data = fh.read()
+        line = data[int(detail):].split(b"\n", 1)[0].strip()
+        try:
+            line.decode("utf8")
+        except UnicodeDecodeError as exc:
+            return exc
+        return UnicodeDecodeError("utf-8", line, 0, 1, "invalid header")
     if rc == PF_FASTA_EBYTE:
         return KeyError(int(detail))
     if rc == PF_FASTA_ENOHEADER:
@@ -50,7 +61,7 @@ def parse_fasta(data: bytes) -> Tuple[np.ndarray, List[str]]:
     n, l, detail = C.c_int32(0), C.c_int32(0), C.c_int64(0)
     rc = lib.pf_parse_fasta(data, len(data), idx.ctypes.data, idx.size, spans.ctypes.data, n_max,
                             C.byref(n), C.byref(l), C.byref(detail))
-    exc = parse_error(rc, l.value, detail.value)
+    exc = parse_error(rc, l.value, detail.value, data=data)
     if exc is not None:
         raise exc
     ids = [data[int(spans[2 * i]):int(spans[2 * i] + spans[2 * i + 1])].decode("utf8") for i in range(n.value)]
