@@ -14,11 +14,13 @@ Additive flags (not in the reference): ``--device`` / ``--devices 0,1,...`` (one
 process per GPU; ``--shard files`` - the default - deals the files to the GPUs, ``--shard sites``
 spreads every alignment over them: each rank holds a block of sites, RCCL all-reduces inside
 ``pf_forward_sharded``, rank 0 writes the outputs), ``--batch`` (same-shape alignments per launch;
-default: fill a token budget per shape), ``--io-threads``, ``--gpu-streams``, ``--python-io``,
+default: fill a token budget per shape), ``--io-threads``, ``--gpu-streams``, ``--precise``, ``--python-io``,
 ``--bench`` (print a JSON timing line).  Scheduling lives in
 ``phyloformer_amd/scheduler.py``: files are bucketed by shape, parsed ahead of the
-GPU and written behind it.  Unlike the reference, a non-FASTA entry aborts the run
-before the first forward instead of when the loop reaches it.
+GPU and written behind it.  A directory entry without a FASTA extension, or a file that does
+not parse, has the reference's side effects (infer_alns.py:97-117): every entry in front of it
+(in ``glob`` order, as there) gets its output, nothing behind it does, then the reference's
+exception is raised; the multi-GPU modes, which have no counterpart, refuse such a directory up front.
 The forward pass runs in ``libphyloformer_amd.so``; there is no CPU fallback.
 """
 import argparse
@@ -59,6 +61,11 @@ def build_parser():
     parser.add_argument("--gpu-streams", type=int, default=2,
                         help="engines (HIP streams, one host thread each) per GPU; 2 hides the host-side gaps "
                              "of a synchronous forward, 1 = one launch sequence at a time")
+    parser.add_argument("--precise", choices=["auto", "always", "never"], default="auto",
+                        help="float64 kernels: auto = for alignments of fewer than 32 sites, at most 4 sequences or fewer "
+                             "than 1024 pair-site tokens (where the fp32 reference itself is ill-conditioned); always = every "
+                             "alignment (input that is nothing like an alignment - random residues, all-gap columns -; "
+                             "50-100 x slower); never = the split-bf16 MFMA kernels on every shape")
     parser.add_argument("--python-io", action="store_true",
                         help="use the pure-Python FASTA parser and PHYLIP writer instead of the native ones")
     parser.add_argument("--worker", default=None, help=argparse.SUPPRESS)   # "r/W": share r of W of the files
@@ -136,6 +143,8 @@ def main(argv=None):
     engines = [model.engine]
     if args.batch != 1:
         engines += [scheduler.cli_engine(model.weights, args.device) for _ in range(max(1, args.gpu_streams) - 1)]
+    for e in engines:
+        e.set_option("precise", {"auto": -1, "always": 1, "never": 0}[args.precise])
     if len(engines) > 1:
         # several engines already keep several streams busy; each splitting its batches over two more only adds
         # contention (tools/cli_bench.py, same box: 505 against 498 alignments/s)
@@ -172,6 +181,7 @@ def run_site_sharded(args, paths, rank, world, out_dir, tqdm):
     t0 = time.perf_counter()
     weights = load_weights(args.weights)
     engine = scheduler.cli_engine(weights, args.device)
+    engine.set_option("precise", {"auto": -1, "always": 1, "never": 0}[args.precise])
     load_s = time.perf_counter() - t0
     group = None
     try:

@@ -159,7 +159,9 @@ class DirectoryRunner:
         """``<stem>.phy`` of a whole launch: formatted and written on native threads (infer_alns.py:105-117)."""
         from .hostio import write_phylip
         outs = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.phy") for g in group]
-        write_phylip([g[1] for g in group], n, preds, outs, self.io_threads)
+        # (at most 4 threads: creating files in ONE directory from 8 / 16 threads is a lock convoy on the directory -
+        # 4,096 outputs took 0.98 / 1.19 s instead of 0.01 s, profiles/r05c_cli_bench.txt)
+        write_phylip([g[1] for g in group], n, preds, outs, min(self.io_threads, 4))
 
     def _gpu_worker(self, engine, jobs: "queue.Queue", writers, pending, errors: list):
         while True:

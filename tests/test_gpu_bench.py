@@ -71,7 +71,12 @@ def test_bench_force_dist_runs_fourteen_collectives():
     assert set(cases) == {"configs[2] 60x500", "configs[3] 60x2000"}
     for c in cases.values():
         assert c["entry_point"] == "pf_forward_sharded_device" and c["collectives"] == 14 and c["ok"] and c["max_abs_err"] < 2e-5
-    assert line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is True
+    assert line["max_abs_err_ok"] is True and line["ranks_bit_identical"] is None      # one rank: nothing to compare
+    # the strong-scaling case (one 60 x 2000 alignment per step through the sharded entry point): 7 collectives, the
+    # bits of the unsharded forward, and the build's identity on the line
+    one = line["configs"]["60x2000 x1 sites-sharded x1"]
+    assert one["collectives_per_alignment"] == 7 and one["bit_identical_to_pf_forward"] is True and one["scaling"] == "strong"
+    assert cfg["build"]["sched_strategy"] == "iterative-ilp" and cfg["build"]["sched_fallback"] is False and len(cfg["build"]["kernel_hash"]) == 16
     c3 = line["configs"]["configs[3] 60x2000 sites-sharded x1"]
     assert c3["sites_per_rank"] == 2000 and c3["alignments_per_s"] > 0 and c3["max_abs_err"] == cases["configs[3] 60x2000"]["max_abs_err"]
 

@@ -36,5 +36,14 @@ if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main and len(sys.argv) > 2:
     rec = {"kernel": "k_main<MID>", "tokens_per_launch": tokens, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
            "hbm_bytes_per_launch": hbm, "hbm_bytes_per_token": hbm / tokens,
            "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section)"}
+    # tie the counters to the library they were taken with (bench.py refuses them for another kernel_hash)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from phyloformer_amd import engine
+        b = engine.build_info()
+        rec.update({"kernel_hash": b["kernel_hash"], "source_hash": b["source_hash"], "sched_strategy": b["sched_strategy"]})
+    except Exception as exc:  # noqa: BLE001
+        rec["kernel_hash"] = None
+        print("pmc_summary: no build info:", exc)
     json.dump(rec, open(os.path.join(out, "pmc_k_main.json"), "w"), indent=1)
     print(rec)
