@@ -62,7 +62,7 @@ def build_parser():
                         help="engines (HIP streams, one host thread each) per GPU; 2 hides the host-side gaps "
                              "of a synchronous forward, 1 = one launch sequence at a time")
     parser.add_argument("--precise", choices=["auto", "always", "never"], default="auto",
-                        help="float64 kernels: auto = for alignments of fewer than 32 sites, at most 4 sequences or fewer "
+                        help="float64 kernels: auto = for alignments of fewer than 64 sites, at most 4 sequences or fewer "
                              "than 1024 pair-site tokens (where the fp32 reference itself is ill-conditioned); always = every "
                              "alignment (input that is nothing like an alignment - random residues, all-gap columns -; "
                              "50-100 x slower); never = the split-bf16 MFMA kernels on every shape")

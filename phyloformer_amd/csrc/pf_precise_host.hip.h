@@ -11,11 +11,12 @@
 // path from (N, L_total) alone, so all ranks issue the same sequence).
 
 // Which alignments take the float64 path: a function of the alignment's global shape only (never of the batch).
-//   L_total < PRECISE_MAX_SITES : rows shorter than one 32-site tile of k_main.  The distance is a MEAN over sites;
+//   L_total < PRECISE_MAX_SITES : rows shorter than two 32-site tiles of k_main.  The distance is a MEAN over sites;
 //                                 with few sites the rounding errors of the split-bf16 products do not average out.
-//                                 Measured (profiles/r05_precise_sweep.txt, r05_adversarial_study.txt): every case over
-//                                 1e-4 in the round-4 soaks had <= 7 sites; simulated alignments of 20-24 sites reach
-//                                 6e-5 ... 1.0e-4, of >= 100 sites <= 2.3e-5.
+//                                 Measured (profiles/r05_precise_sweep.txt, r05_adversarial_study.txt, the soak of
+//                                 tests/test_gpu_precise.py): every case over 1e-4 in the round-4 soaks had <= 7 sites;
+//                                 simulated alignments of 20-32 sites reach 6e-5 ... 1.05e-4, of 33-48 sites 8e-5, of
+//                                 >= 100 sites <= 2.3e-5.
 //   N <= PRECISE_MAX_SEQS       : 2-4 sequences (1-6 pairs): the column attention normalises by sums of 1-6 terms;
 //                                 errors of 1e-4 ... 3e-4 up to 64 sites
 //   P * L_total < PRECISE_MAX_TOKENS : the remaining small cases (5 x 33 ... 6 x 64: up to 3e-4)
@@ -23,7 +24,7 @@
 // up to 35 % of the residues randomised: <= 8e-5, section 5 of DESIGN.md); uniformly random residues, two-letter
 // alphabets or all-gap columns do not at any size (2e-4 ... 3e-3, where the fp32 reference itself is up to 2.6e-3 from
 // float64) - option "precise" = 1 / `infer_alns.py --precise always` computes those in float64.
-constexpr int PRECISE_MAX_SITES = 32;
+constexpr int PRECISE_MAX_SITES = 64;
 constexpr int PRECISE_MAX_SEQS = 4;
 constexpr long PRECISE_MAX_TOKENS = 1024;
 bool use_precise(const pf_handle* h, int N, int L_total) {

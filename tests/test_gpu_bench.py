@@ -129,7 +129,10 @@ def test_bench_default_line_carries_the_contract():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["global_batch"]) < 0.02 * d["config"]["global_batch"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["launches"] == 18
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 0.34 and r["traffic"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 0.34
+    # traffic: the committed PMC figures IF they were taken with this library's kernels, else null with the reason
+    assert (r["traffic"] or 0) > 0 or "stale" in r["traffic_source"] or "absent" in r["traffic_source"]
+    assert d["config"]["build"]["kernel_hash"] in r["traffic_source"] or r["traffic"] is None
     assert len(d["configs"]) == 5 and all(v["alignments_per_s"] > 0 for v in d["configs"].values())
     assert d["value_pcie_inclusive"] <= d["value"] * 1.05
     # the metric's second half: max-abs error against the reference's outputs for every BASELINE shape

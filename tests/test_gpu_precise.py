@@ -47,12 +47,12 @@ def test_float64_path_matches_float64_oracle(weights):
 
 
 def test_shape_selection_is_by_shape_only_and_batch_invariant(engines, weights):
-    """Alignments of < 32 sites, <= 4 sequences or < 1024 tokens take the float64 path wherever they travel: alone, in
+    """Alignments of < 64 sites, <= 4 sequences or < 1024 tokens take the float64 path wherever they travel: alone, in
     a batch, in a batch cut into workspace chunks - identical bits; larger ones keep the default kernels' bits
     (precise = 0 gives the same result)."""
     e = engines("pf")
     w = weights("pf").tensors
-    for (n, l, b) in [(9, 7, 5), (4, 120, 3), (6, 40, 4), (30, 15, 2)]:          # selected
+    for (n, l, b) in [(9, 7, 5), (4, 120, 3), (6, 40, 4), (30, 15, 2), (25, 63, 1)]:          # selected
         idx = simulate_batch(b, n, l, seed=n * 100 + l)
         got = e.forward(idx)
         assert np.array_equal(np.stack([e.forward(x) for x in idx]), got)
@@ -94,7 +94,7 @@ def test_float64_path_site_sharded_over_a_real_communicator(weights):
 
 
 def _routed_to_float64(n, l):
-    return l < 32 or n <= 4 or n * (n - 1) // 2 * l < 1024       # pf_precise_host.hip.h::use_precise
+    return l < 64 or n <= 4 or n * (n - 1) // 2 * l < 1024       # pf_precise_host.hip.h::use_precise
 
 
 def _soak_cases(n_cases, seed):
@@ -103,8 +103,10 @@ def _soak_cases(n_cases, seed):
     ls = [1, 2, 3, 4, 5, 7, 9, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 129, 200]
     for c in range(n_cases):
         n, l = int(rng.choice(ns)), int(rng.choice(ls))
+        while n * (n - 1) // 2 * l > 40_000:          # (the fp64 numpy oracle is what this test waits for)
+            n, l = int(rng.choice(ns)), int(rng.choice(ls))
         b = int(rng.integers(1, 4))
-        if n * (n - 1) // 2 * l * b > 30_000:
+        if n * (n - 1) // 2 * l * b > 16_000:
             b = 1
         mode = int(rng.integers(3))          # 0: simulated, 1: simulated with gaps, 2: uniformly random residues
         yield c, CKPTS[c % len(CKPTS)], n, l, b, mode, int(rng.integers(1 << 30))
@@ -118,6 +120,11 @@ def test_soak_every_accepted_shape_within_the_reference_error(engines, weights):
     documented out-of-distribution envelope 2e-4 x max(1, largest distance) on the default kernels.  Every case finite
     and bit-identical one alignment at a time."""
     bad, worst = [], {"default, simulated": 0.0, "default, random residues (relative)": 0.0, "float64 vs fp64 oracle": 0.0}
+    try:        # the oracle's BLAS on all 256 hardware threads of the GPU host oversubscribes: 32 is 3 x faster
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=32)
+    except Exception:  # noqa: BLE001
+        limit = None
     for c, ck, n, l, b, mode, seed in _soak_cases(240, 20261002):
         if mode == 2:
             idx = np.random.default_rng(seed).integers(0, 22, (b, n, l)).astype(np.uint8)
