@@ -125,7 +125,7 @@ const char* pf_last_error(const pf_handle_t* h);
  *                      pair-site tokens: the distance is a mean over sites, and with few of them the rounding of
  *                      the split-bf16 products does not average out below 1e-4), 0 = never, 1 = always (any
  *                      shape in float64: for input that is nothing like an alignment - uniformly random
- *                      residues, all-gap columns - where the default kernels reach 2e-4 ... 3e-3; 50-100 x slower).
+ *                      residues, all-gap columns - where the default kernels reach 2e-4 ... 3e-3; 3-9 x slower).
  *                      The choice never depends on the batch.
  */
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);

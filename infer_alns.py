@@ -65,7 +65,7 @@ def build_parser():
                         help="float64 kernels: auto = for alignments of fewer than 64 sites, at most 4 sequences or fewer "
                              "than 1024 pair-site tokens (where the fp32 reference itself is ill-conditioned); always = every "
                              "alignment (input that is nothing like an alignment - random residues, all-gap columns -; "
-                             "50-100 x slower); never = the split-bf16 MFMA kernels on every shape")
+                             "3-9 x slower); never = the split-bf16 MFMA kernels on every shape")
     parser.add_argument("--python-io", action="store_true",
                         help="use the pure-Python FASTA parser and PHYLIP writer instead of the native ones")
     parser.add_argument("--worker", default=None, help=argparse.SUPPRESS)   # "r/W": share r of W of the files

@@ -208,6 +208,7 @@ struct pf_handle {
     int tile_force = -1;
     // float64 path for ill-conditioned shapes (pf_precise.hip.h): option "precise" -1 = by shape, 0 = never, 1 = always
     int precise = -1;
+    bool precise_ffn_valu = false;   // option "precise_ffn_valu": the float64 FFN on the VALU instead of the matrix cores (cross-check)
     PreciseWeights pw;
     char* wsp = nullptr; size_t wsp_bytes = 0;
     // sticky "residue byte > 21 seen" flag: pinned host memory the kernels write through its device alias
@@ -1075,6 +1076,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
     else if (k == "precise") h->precise = value < 0 ? -1 : (value != 0);
+    else if (k == "precise_ffn_valu") h->precise_ffn_valu = value != 0;
     else if (k == "phase_prof") {
         if (value && !h->phase_prof) { HIPCHK(h, hipMalloc((void**)&h->phase_prof, 64)); h->owned.push_back(h->phase_prof); }
         if (h->phase_prof) HIPCHK(h, hipMemset(h->phase_prof, 0, 64));

@@ -90,6 +90,93 @@ __global__ void __launch_bounds__(PT) kp_attn_stats(StatsArgs a) {
     if (tid < SROW) a.part[((size_t)line * a.nchunk + ch) * SROW + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
+// The same statistics with the projections on the matrix cores (v_mfma_f64_16x16x4_f64; layouts as kp_ffn_mfma below):
+// one wave = 16 elements of the line at a time, lane (g, j) holds channels 16 g ... 16 g + 15 of element j.  The fused
+// 72 x 64 projection [Wv; Wq; Wk] is five 16-row tiles: tile T < 4 is head T of v (register r of lane (g, j) = channel
+// 16 T + g + 4 r), tile 4 leaves q[g] in register 0 and k[g] in register 1 of lane (g, j).  Each lane accumulates the
+// contributions of its own elements (k'[T] comes from lane (T, j) by one shuffle); the 16 element lanes of a lane group
+// are summed once per wave at the end, the four waves in fixed order.  Block = (line, chunk of CHUNK_MFMA elements).
+typedef double d4s __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(PT) kp_attn_stats_mfma(StatsArgs a) {
+    __shared__ double red[4][SROW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int line = blockIdx.x / a.nchunk, ch = blockIdx.x - line * a.nchunk;
+    const int nelem = a.col ? a.P : a.L;
+    const double* gam = a.w.g + 16 * g;       // (re-read per tile from L1: 64 registers are worth more than 32 loads)
+    const double* bet = a.w.b + 16 * g;
+    const double bq = a.w.bqk[g], bk = a.w.bqk[4 + g];
+    d4s skv[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) skv[T] = d4s{0.0, 0.0, 0.0, 0.0};
+    double sq = 0.0, sk = 0.0;
+    const int e_end = min(nelem, (ch + 1) * CHUNK_MFMA);
+    for (int e0 = ch * CHUNK_MFMA + 16 * w; e0 < e_end; e0 += 64) {
+        const int e = e0 + j;
+        const bool valid = e < e_end;
+        const size_t tok = token_of(a.col, line, valid ? e : e0, a.P, a.L);
+        double xn[16];
+        {
+            const double* p = a.x + tok * E + 16 * g;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { xn[m] = p[m]; s += xn[m]; }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const double mu = s * (1.0 / 64.0);
+            double v = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { xn[m] -= mu; v = fma(xn[m], xn[m], v); }
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const double sd = sqrt(v * (1.0 / 64.0) + 1e-5);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) xn[m] = xn[m] / sd * gam[m] + bet[m];
+        }
+        d4s qk = d4s{bq, bk, 0.0, 0.0};
+        {
+            const double* a4 = a.w.a72 + (size_t)4 * 16 * 64 + lane;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) qk = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s * 64], xn[s], qk, 0, 0, 0);
+        }
+        const double qp = valid ? elu1(qk[0]) : 0.0, kp = valid ? elu1(qk[1]) : 0.0;     // q'[g], k'[g] of element j
+        sq += qp;
+        sk += kp;
+        if (valid) a.q[tok * 4 + g] = qp;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            d4s v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = a.w.bv[16 * T + g + 4 * r];
+            const double* aT = a.w.a72 + (size_t)T * 16 * 64 + lane;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) v = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[s * 64], xn[s], v, 0, 0, 0);
+            const double kT = __shfl(kp, 16 * T + j, 64);          // k'[T] of element j (0 for an element past the end)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) skv[T][r] = fma(kT, v[r], skv[T][r]);   // attention.py:187-188, channel 16 T + g + 4 r
+        }
+    }
+    // sum over the 16 element lanes of each lane group, then over the four waves (fixed order)
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) skv[T][r] += __shfl_xor(skv[T][r], m, 64);
+        sq += __shfl_xor(sq, m, 64);
+        sk += __shfl_xor(sk, m, 64);
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][16 * T + g + 4 * r] = skv[T][r];
+        red[w][64 + g] = sq;
+        red[w][68 + g] = sk;
+    }
+    __syncthreads();
+    if (tid < SROW) a.part[((size_t)line * a.nchunk + ch) * SROW + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
 // part[line][nchunk][72] -> stats[line][72], chunks in index order
 __global__ void __launch_bounds__(PT) kp_stats_fin(const double* part, double* stats, int nlines, int nchunk) {
     const int i = blockIdx.x * PT + threadIdx.x;
@@ -172,6 +259,118 @@ __global__ void __launch_bounds__(PT) kp_ffn(FfnArgs a) {
     }
 }
 
+// ---- the same on the matrix cores: v_mfma_f64_16x16x4_f64 -------------------------------------------------
+// One wave = 16 tokens on the N side.  Lane (g = lane >> 4, j = lane & 15) holds the 16 channels 16 g ... 16 g + 15
+// of token j - 128 contiguous bytes of x.  Operand layouts (cdna_hip_programming.md): A[i][k] in lane i + 16 k,
+// B[k][j] in lane j + 16 k, D[row = g + 4 r][col = j] in register r of lane (g, j).  The K order of each product and
+// the row order of each output tile are free, and chosen so that activations never move between lanes:
+//   GEMM1  K step s takes channel 16 kq + s from lane group kq            -> B operand = the lane's own xn[s]
+//   GEMM1  D tile T: register r of lane (g, j) = hidden unit 16 T + g + 4 r
+//   GEMM2  K step (T, r) takes hidden unit 16 T + kq + 4 r from lane group kq  -> B operand = GELU of D register r
+//   GEMM2  D tile Tc: row i stands for channel 16 (i & 3) + 4 Tc + (i >> 2), so register r of lane (g, j) is channel
+//          16 g + 4 Tc + r: the residual's own layout
+// (the A fragments are packed accordingly on the host, pf_precise_host.hip.h).  512 MFMAs per 16 tokens; the
+// 256 erf evaluations per token run on the VALU beside another wave's MFMAs.
+// erf-GELU in double without ocml's erf (four divergent ranges, ~2,000 cycles per wave: it was 70 % of the FFN kernel):
+//   gelu(h) = max(h, 0) - |h| Q(|h|),  Q(u) = erfc(u / sqrt 2) / 2 = exp(-u^2 / 2) R(u),
+//   R(u) (1 + u) = a degree-22 polynomial in t = (u - 4) / (u + 4)  (Chebyshev fit on u in [0, inf), |relative error|
+//   of R <= 2.4e-15, coefficients generated with scipy's erfcx; |gelu error| <= 1.8e-15 over |h| <= 40 against
+//   0.5 h (1 + erf(h / sqrt 2)) evaluated in double).  Branch-free: one division, one exp, 23 FMAs.
+__device__ __forceinline__ double gelu_f64(double h) {
+    constexpr double Q[23] = {0x1.e361ea6fba145p-2, -0x1.8c18f2086e47cp-4, 0x1.cabd72a6120b9p-7, 0x1.d4969f10f90d4p-6,
+                              -0x1.07c3c25842975p-5, 0x1.25dd720375999p-6, -0x1.47d5fc6944b2cp-8, -0x1.2b7f5644197fap-12,
+                              0x1.6c5380196e928p-11, -0x1.8c1283b1235e3p-14, -0x1.707b3dae24d79p-14, 0x1.64919115d4a57p-16,
+                              0x1.c9344f4725c3dp-17, -0x1.cdc5363466f39p-19, -0x1.5e69413cc4adcp-19, 0x1.c1cd90ff96cf7p-22,
+                              0x1.26fb2b6228421p-21, -0x1.005dbc607bf3dp-26, -0x1.d50a583370aa4p-24, -0x1.1cca57b6a492fp-27,
+                              0x1.241e7aeedd9aap-26, 0x1.b830e247ca68bp-30, -0x1.925d735408ab7p-30};
+    const double u = fabs(h);
+    const double r = 1.0 / ((u + 4.0) * (u + 1.0));
+    const double t = (u - 4.0) * (u + 1.0) * r;
+    double p = Q[22];
+#pragma unroll
+    for (int k = 21; k >= 0; --k) p = fma(p, t, Q[k]);
+    const double q = exp(-0.5 * u * u) * p * (u + 4.0) * r;
+    return fmax(h, 0.0) - u * q;
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(PT) kp_ffn_mfma(FfnArgs a) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const size_t tok = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;
+    const bool valid = tok < a.ntok;
+    double x[16], xn[16];
+    {
+        const double* p = a.x + (valid ? tok : 0) * E + 16 * g;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = valid ? p[m] : 0.0;
+    }
+    {   // nn.LayerNorm(64): the token's channels sit in the four lanes (g, j), g = 0..3
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) s += x[m];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const double mu = s * (1.0 / 64.0);
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { xn[m] = x[m] - mu; v = fma(xn[m], xn[m], v); }
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const double sd = sqrt(v * (1.0 / 64.0) + 1e-5);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) xn[m] = xn[m] / sd * a.w.g[16 * g + m] + a.w.b[16 * g + m];
+    }
+    d4 y[4];
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[tc][r] = a.w.b2[16 * g + 4 * tc + r];
+    // The A fragments of one hidden tile T (16 of W1 + 16 of W2 = 16 KB) are the same for the block's four waves: they
+    // are staged through LDS, double-buffered - every thread fetches 8 doubles of tile T + 1 while tile T is consumed.
+    // (Read straight from L2 by every wave the fragments were 16 KB per TOKEN of L2 traffic: 6.5 TB/s, the kernel's bound.)
+    __shared__ double frag[2][2 * 16 * 64];
+    const int tid = threadIdx.x;
+    {
+        const double *s1 = a.w.a1, *s2 = a.w.a2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { frag[0][tid + 256 * k] = s1[tid + 256 * k]; frag[0][1024 + tid + 256 * k] = s2[tid + 256 * k]; }
+    }
+    __syncthreads();
+    for (int T = 0; T < 16; ++T) {
+        double n1[4], n2[4];
+        const int Tn = min(T + 1, 15);
+        {
+            const double *s1 = a.w.a1 + (size_t)Tn * 1024, *s2 = a.w.a2 + (size_t)Tn * 1024;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { n1[k] = s1[tid + 256 * k]; n2[k] = s2[tid + 256 * k]; }
+        }
+        const double* f = frag[T & 1];
+        d4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = a.w.b1[16 * T + g + 4 * r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) h = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s * 64 + lane], xn[s], h, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double act = gelu_f64(h[r]);                                                   // nn.GELU(): erf form
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc)
+                y[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1024 + (r * 4 + tc) * 64 + lane], act, y[tc], 0, 0, 0);
+        }
+        double* fn = frag[(T + 1) & 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { fn[tid + 256 * k] = n1[k]; fn[1024 + tid + 256 * k] = n2[k]; }
+        __syncthreads();
+    }
+    if (valid) {
+        double* p = a.x + tok * E + 16 * g;
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[4 * tc + r] = x[4 * tc + r] + y[tc][r];
+    }
+}
+
 // ---- head (model.py:158-164, 182-185): per pair, sum over this rank's sites of softplus(w . x + b) ------
 __global__ void __launch_bounds__(PT) kp_head(HeadArgs a) {
     const int lane = threadIdx.x & 63, line = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -200,13 +399,17 @@ __global__ void __launch_bounds__(PT) kp_to_float(const double* src, float* dst,
 
 #define PFP_GRID(n) dim3((unsigned)(((n) + PT - 1) / PT))
 void launch_embed(hipStream_t s, size_t grid, const EmbedArgs& a) { hipLaunchKernelGGL(kp_embed, dim3((unsigned)grid), dim3(PT), 0, s, a); }
-void launch_attn_stats(hipStream_t s, size_t grid, const StatsArgs& a) { hipLaunchKernelGGL(kp_attn_stats, dim3((unsigned)grid), dim3(PT), 0, s, a); }
+void launch_attn_stats(hipStream_t s, size_t grid, const StatsArgs& a, bool valu) {
+    if (valu) hipLaunchKernelGGL(kp_attn_stats, dim3((unsigned)grid), dim3(PT), 0, s, a);
+    else hipLaunchKernelGGL(kp_attn_stats_mfma, dim3((unsigned)grid), dim3(PT), 0, s, a);
+}
 void launch_stats_fin(hipStream_t s, const double* part, double* stats, int nlines, int nchunk) {
     hipLaunchKernelGGL(kp_stats_fin, PFP_GRID((size_t)nlines * SROW), dim3(PT), 0, s, part, stats, nlines, nchunk);
 }
 void launch_attn_apply(hipStream_t s, size_t grid, const ApplyArgs& a) { hipLaunchKernelGGL(kp_attn_apply, dim3((unsigned)grid), dim3(PT), 0, s, a); }
-void launch_ffn(hipStream_t s, const FfnArgs& a) {
-    hipLaunchKernelGGL(kp_ffn, dim3((unsigned)((a.ntok + FFN_NT - 1) / FFN_NT)), dim3(PT), 0, s, a);
+void launch_ffn(hipStream_t s, const FfnArgs& a, bool valu) {
+    if (valu) hipLaunchKernelGGL(kp_ffn, dim3((unsigned)((a.ntok + FFN_NT - 1) / FFN_NT)), dim3(PT), 0, s, a);
+    else hipLaunchKernelGGL(kp_ffn_mfma, dim3((unsigned)((a.ntok + 63) / 64)), dim3(PT), 0, s, a);
 }
 void launch_head(hipStream_t s, const HeadArgs& a) { hipLaunchKernelGGL(kp_head, dim3((unsigned)((a.nlines + 3) / 4)), dim3(PT), 0, s, a); }
 void launch_out(hipStream_t s, const double* osum, float* out, int n, double l_total) {

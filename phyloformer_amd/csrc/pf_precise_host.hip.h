@@ -50,8 +50,8 @@ int prepare_precise_weights(pf_handle* h, const pf_weights_t* w, PreciseWeights*
     const size_t o_table = put((size_t)NA * E);
     for (int a = 0; a < NA; ++a)
         for (int c = 0; c < E; ++c) D[o_table + (size_t)a * E + c] = std::max((double)emb_w[c * NA + a] + (double)emb_b[c], 0.0);
-    struct AO { size_t g, b, wqk, bqk, wvT, bv, woT, bo; };
-    struct FO { size_t g, b, w1T, b1, w2T, b2; };
+    struct AO { size_t g, b, wqk, bqk, wvT, bv, woT, bo, a72; };
+    struct FO { size_t g, b, w1T, b1, w2T, b2, a1, a2; };
     const int nb = w->n_blocks;
     std::vector<AO> ro(nb), co(nb);
     std::vector<FO> fo(nb);
@@ -62,6 +62,18 @@ int prepare_precise_weights(pf_handle* h, const pf_weights_t* w, PreciseWeights*
         o.bqk = copy(a.bq, NH); copy(a.bk, NH);
         o.wvT = transposed(a.wv, E, E); o.bv = copy(a.bv, E);
         o.woT = transposed(a.wo, E, E); o.bo = copy(a.bo, E);
+        // A fragments of the fused [Wv; Wq; Wk] projection (pf_precise.hip.h::AttnW)
+        o.a72 = put((size_t)5 * 16 * 64);
+        for (int T = 0; T < 5; ++T)
+            for (int s = 0; s < 16; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 15, c = 16 * (lane >> 4) + s;
+                    double v = 0.0;
+                    if (T < 4) v = (double)a.wv[(size_t)(16 * T + i) * E + c];
+                    else if (i < 4) v = (double)a.wq[(size_t)i * E + c];
+                    else if (i < 8) v = (double)a.wk[(size_t)(i - 4) * E + c];
+                    D[o.a72 + ((size_t)T * 16 + s) * 64 + lane] = v;
+                }
     };
     for (int k = 0; k < nb; ++k) {
         attn(ro[k]);
@@ -71,6 +83,21 @@ int prepare_precise_weights(pf_handle* h, const pf_weights_t* w, PreciseWeights*
         fo[k].g = copy(g, E); fo[k].b = copy(b, E);
         fo[k].w1T = transposed(w1, FF, E); fo[k].b1 = copy(b1, FF);
         fo[k].w2T = transposed(w2, E, FF); fo[k].b2 = copy(b2, E);
+        // v_mfma_f64_16x16x4_f64 A fragments of kp_ffn_mfma (layouts: pf_precise.hip.h::FfnW)
+        fo[k].a1 = put((size_t)16 * 16 * 64);
+        for (int T = 0; T < 16; ++T)
+            for (int s = 0; s < 16; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    D[fo[k].a1 + ((size_t)T * 16 + s) * 64 + lane] = (double)w1[(size_t)(16 * T + (lane & 15)) * E + 16 * (lane >> 4) + s];
+        fo[k].a2 = put((size_t)16 * 4 * 4 * 64);
+        for (int T = 0; T < 16; ++T)
+            for (int r = 0; r < 4; ++r)
+                for (int tc = 0; tc < 4; ++tc)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 15, kq = lane >> 4;
+                        D[fo[k].a2 + (((size_t)T * 4 + r) * 4 + tc) * 64 + lane] =
+                            (double)w2[(size_t)(16 * (i & 3) + 4 * tc + (i >> 2)) * FF + 16 * T + kq + 4 * r];
+                    }
     }
     const size_t o_hw = copy(bl.take(E), E), o_hb = copy(bl.take(1), 1);
     float* dev = nullptr;
@@ -79,11 +106,12 @@ int prepare_precise_weights(pf_handle* h, const pf_weights_t* w, PreciseWeights*
     const double* base = reinterpret_cast<const double*>(dev);
     out->blob = reinterpret_cast<double*>(dev);
     out->table = base + o_table;
-    auto A = [&](const AO& o) { return pfp::AttnW{base + o.g, base + o.b, base + o.wqk, base + o.bqk, base + o.wvT, base + o.bv, base + o.woT, base + o.bo}; };
+    auto A = [&](const AO& o) { return pfp::AttnW{base + o.g, base + o.b, base + o.wqk, base + o.bqk, base + o.wvT, base + o.bv, base + o.woT, base + o.bo, base + o.a72}; };
     for (int k = 0; k < nb; ++k) {
         out->row.push_back(A(ro[k]));
         out->col.push_back(A(co[k]));
-        out->ffn.push_back(pfp::FfnW{base + fo[k].g, base + fo[k].b, base + fo[k].w1T, base + fo[k].b1, base + fo[k].w2T, base + fo[k].b2});
+        out->ffn.push_back(pfp::FfnW{base + fo[k].g, base + fo[k].b, base + fo[k].w1T, base + fo[k].b1, base + fo[k].w2T, base + fo[k].b2,
+                                    base + fo[k].a1, base + fo[k].a2});
     }
     out->hw = base + o_hw; out->hb = base + o_hb;
     return PF_OK;
@@ -151,9 +179,10 @@ int p_stats(pf_handle* h, const PRun& r, const pfp::AttnW& w, int col, double* s
         if (lines) HIPCHK(h, hipMemsetAsync(stats, 0, (size_t)lines * SROW * 8, h->cur));
         return PF_OK;
     }
-    const int nch = pchunks(nelem);
+    const int chunk = h->precise_ffn_valu ? pfp::CHUNK : pfp::CHUNK_MFMA;
+    const int nch = (nelem + chunk - 1) / chunk;
     pfp::StatsArgs a{r.w.x, r.w.q, r.w.part, w, col, r.P, r.Lloc, nch};
-    PF_PLAUNCH(h, pfp::launch_attn_stats(h->cur, (size_t)lines * nch, a));
+    PF_PLAUNCH(h, pfp::launch_attn_stats(h->cur, (size_t)lines * nch, a, h->precise_ffn_valu));
     PF_PLAUNCH(h, pfp::launch_stats_fin(h->cur, r.w.part, stats, lines, nch));
     return PF_OK;
 }
@@ -172,7 +201,7 @@ int p_local(pf_handle* h, const PRun& r, int k) {
     if ((rc = p_stats(h, r, h->pw.col[k], 1, r.w.scol))) return rc;
     if ((rc = p_apply(h, r, h->pw.col[k], 1, r.w.scol))) return rc;
     pfp::FfnArgs f{r.w.x, h->pw.ffn[k], r.ntok()};
-    PF_PLAUNCH(h, pfp::launch_ffn(h->cur, f));
+    PF_PLAUNCH(h, pfp::launch_ffn(h->cur, f, h->precise_ffn_valu));
     if (h->debug_keep) {
         // taps of the float64 path: the residual stream after every block, narrowed to float
         const size_t n = r.ntok() * 64;

@@ -46,6 +46,24 @@ def test_float64_path_matches_float64_oracle(weights):
     print(f"float64 path vs float64 oracle: worst {worst:.3e}")
 
 
+def test_float64_ffn_on_the_matrix_cores_against_the_valu_kernel(weights):
+    """The float64 FFN runs on v_mfma_f64_16x16x4_f64 (kp_ffn_mfma: operand layouts chosen so that activations never
+    move between lanes); option precise_ffn_valu = 1 swaps in the plain VALU kernel.  Both are the float64 oracle's
+    arithmetic up to summation order: within 1e-9 of it and of each other, ragged token counts included."""
+    from phyloformer_amd.engine import Engine
+    for (ck, n, l, b) in [("pf", 7, 33, 2), ("pf_indel", 3, 5, 1), ("pf_base", 11, 90, 1)]:
+        idx = simulate_batch(b, n, l, seed=n * 7 + l, gaps=(ck == "pf_indel"))
+        want = _f64(weights(ck).tensors, idx)
+        out = {}
+        with Engine(weights(ck), 0) as e:
+            e.set_option("precise", 1)
+            for valu in (0, 1):
+                e.set_option("precise_ffn_valu", valu)
+                out[valu] = e.forward(idx).astype(np.float64)
+                assert float(np.abs(out[valu] - want).max()) <= 1e-9 + 6e-8 * float(np.abs(want).max()), (ck, n, l, valu)
+        assert float(np.abs(out[0] - out[1]).max()) <= 1.2e-7 * max(1.0, float(np.abs(want).max()))
+
+
 def test_shape_selection_is_by_shape_only_and_batch_invariant(engines, weights):
     """Alignments of < 64 sites, <= 4 sequences or < 1024 tokens take the float64 path wherever they travel: alone, in
     a batch, in a batch cut into workspace chunks - identical bits; larger ones keep the default kernels' bits
