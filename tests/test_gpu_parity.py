@@ -491,3 +491,29 @@ def test_device_entry_points_survive_out_of_alphabet_bytes(weights, golden):
         assert np.isfinite(out).all() and np.abs(out - want).max() <= 1e-3
         e.free(d_idx)
         e.free(d_out)
+
+
+@pytest.mark.parametrize("ck,n,l,gaps", [("pf", 60, 500, False), ("pf_indel", 200, 500, True)])
+def test_full_size_properties(engines, ck, n, l, gaps):
+    """BASELINE's full sizes (configs[2] 60 x 500, configs[4] gapped 200 x 500), where the oracle takes minutes, through
+    properties that do not depend on the size: sites are exchangeable (the distance is a mean over sites of a function
+    that is permutation-equivariant along them, model.py:166-187), sequences are equivariant (permuting them permutes
+    the distance matrix), an alignment's bits do not depend on its neighbours in the batch, and eight emulated site
+    shards (ragged: 500 = 7 x 63 + 59) give the unsharded distances."""
+    from phyloformer_amd.phylip import vec_to_matrix
+    e = engines(ck)
+    idx = simulate_batch(1, n, l, seed=2025 + n, gaps=gaps)[0]
+    base = e.forward(idx)
+    scale = max(1.0, float(np.abs(base).max()))
+    assert np.isfinite(base).all() and (base > 0).all()
+    rng = np.random.default_rng(n)
+    sites = rng.permutation(l)
+    assert float(np.abs(e.forward(idx[:, sites]) - base).max()) <= 2e-5 * scale
+    seqs = rng.permutation(n)
+    dm, dmp = vec_to_matrix(base, n), vec_to_matrix(e.forward(idx[seqs]), n)
+    assert float(np.abs(dmp - dm[np.ix_(seqs, seqs)]).max()) <= 2e-5 * scale
+    if n <= 60:
+        other = simulate_batch(2, n, l, seed=7, gaps=gaps)
+        both = e.forward(np.stack([other[0], idx, other[1]]))
+        assert np.array_equal(both[1], base)                               # batch invariance, bitwise
+    assert float(np.abs(e.forward_shards_emulated(idx, 8) - base).max()) <= 2e-5 * scale
