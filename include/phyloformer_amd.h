@@ -121,7 +121,7 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "embed_mfma" int   1 = compute block 0's row statistics with the MFMA kernel (k_main<FIRST>) instead of
  *                      the residue-pair table lookup (k_embed); cross-check only, same results to fp32 noise
  *   "precise"    int   which alignments take the float64 path (csrc/pf_precise.hip.h): -1 (default) = chosen from
- *                      the alignment's shape (fewer than 64 sites, at most 4 sequences, or fewer than 1024
+ *                      the alignment's shape (fewer than 64 sites, at most 4 sequences, or fewer than 8192
  *                      pair-site tokens: the distance is a mean over sites, and with few of them the rounding of
  *                      the split-bf16 products does not average out below 1e-4), 0 = never, 1 = always (any
  *                      shape in float64: for input that is nothing like an alignment - uniformly random

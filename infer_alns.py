@@ -63,7 +63,7 @@ def build_parser():
                              "of a synchronous forward, 1 = one launch sequence at a time")
     parser.add_argument("--precise", choices=["auto", "always", "never"], default="auto",
                         help="float64 kernels: auto = for alignments of fewer than 64 sites, at most 4 sequences or fewer "
-                             "than 1024 pair-site tokens (where the fp32 reference itself is ill-conditioned); always = every "
+                             "than 8192 pair-site tokens (where the fp32 reference itself is ill-conditioned); always = every "
                              "alignment (input that is nothing like an alignment - random residues, all-gap columns -; "
                              "3-9 x slower); never = the split-bf16 MFMA kernels on every shape")
     parser.add_argument("--python-io", action="store_true",

@@ -19,14 +19,16 @@
 //                                 >= 100 sites <= 2.3e-5.
 //   N <= PRECISE_MAX_SEQS       : 2-4 sequences (1-6 pairs): the column attention normalises by sums of 1-6 terms;
 //                                 errors of 1e-4 ... 3e-4 up to 64 sites
-//   P * L_total < PRECISE_MAX_TOKENS : the remaining small cases (5 x 33 ... 6 x 64: up to 3e-4)
+//   P * L_total < PRECISE_MAX_TOKENS : small alignments of any proportion: 5 x 33 ... 6 x 64 reach 3e-4, and the tail is
+//                                 long - one gapped 7 x 65 alignment in 960 soak cases of other seeds sat at 2.0e-4
+//                                 (profiles/r05l_soak_seeds.txt).  Below 8,192 tokens float64 costs < 0.2 ms.
 // Alignments this rule keeps on the default kernels hold 1e-4 when they look like alignments (simulated, gapped,
 // up to 35 % of the residues randomised: <= 8e-5, section 5 of DESIGN.md); uniformly random residues, two-letter
 // alphabets or all-gap columns do not at any size (2e-4 ... 3e-3, where the fp32 reference itself is up to 2.6e-3 from
 // float64) - option "precise" = 1 / `infer_alns.py --precise always` computes those in float64.
 constexpr int PRECISE_MAX_SITES = 64;
 constexpr int PRECISE_MAX_SEQS = 4;
-constexpr long PRECISE_MAX_TOKENS = 1024;
+constexpr long PRECISE_MAX_TOKENS = 8192;
 bool use_precise(const pf_handle* h, int N, int L_total) {
     if (h->precise >= 0) return h->precise != 0;
     const long P = (long)N * (N - 1) / 2;

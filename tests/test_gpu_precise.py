@@ -65,12 +65,12 @@ def test_float64_ffn_on_the_matrix_cores_against_the_valu_kernel(weights):
 
 
 def test_shape_selection_is_by_shape_only_and_batch_invariant(engines, weights):
-    """Alignments of < 64 sites, <= 4 sequences or < 1024 tokens take the float64 path wherever they travel: alone, in
+    """Alignments of < 64 sites, <= 4 sequences or < 8192 tokens take the float64 path wherever they travel: alone, in
     a batch, in a batch cut into workspace chunks - identical bits; larger ones keep the default kernels' bits
     (precise = 0 gives the same result)."""
     e = engines("pf")
     w = weights("pf").tensors
-    for (n, l, b) in [(9, 7, 5), (4, 120, 3), (6, 40, 4), (30, 15, 2), (25, 63, 1)]:          # selected
+    for (n, l, b) in [(9, 7, 5), (4, 120, 3), (6, 40, 4), (30, 15, 2), (25, 63, 1), (9, 64, 2), (12, 100, 1)]:   # selected
         idx = simulate_batch(b, n, l, seed=n * 100 + l)
         got = e.forward(idx)
         assert np.array_equal(np.stack([e.forward(x) for x in idx]), got)
@@ -81,7 +81,7 @@ def test_shape_selection_is_by_shape_only_and_batch_invariant(engines, weights):
             assert np.array_equal(e.forward(idx), got)
         finally:
             e.set_option("ws_limit_mb", 24576)
-    for (n, l, b) in [(9, 64, 2), (20, 200, 1), (5, 103, 3)]:                    # not selected: the default kernels
+    for (n, l, b) in [(12, 128, 2), (20, 200, 1), (40, 70, 1)]:                  # not selected: the default kernels
         idx = simulate_batch(b, n, l, seed=n * 100 + l)
         got = e.forward(idx)
         e.set_option("precise", 0)
@@ -112,7 +112,7 @@ def test_float64_path_site_sharded_over_a_real_communicator(weights):
 
 
 def _routed_to_float64(n, l):
-    return l < 64 or n <= 4 or n * (n - 1) // 2 * l < 1024       # pf_precise_host.hip.h::use_precise
+    return l < 64 or n <= 4 or n * (n - 1) // 2 * l < 8192       # pf_precise_host.hip.h::use_precise
 
 
 def _soak_cases(n_cases, seed):
