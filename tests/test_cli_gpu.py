@@ -51,6 +51,32 @@ def test_cli_error_behaviour(repo, tmp_path):
     assert r.returncode != 0 and "TypeError" in r.stderr                            # -o omitted, :53,90
 
 
+@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue"])
+def test_cli_bad_entry_leaves_what_the_reference_leaves(repo, tmp_path, scenario):
+    """The whole CLI on the GPU against the fixture the REAL reference CLI produced (oracle/gen_golden_cli_errors.py):
+    the same file names; the entries `glob` lists in front of the offender get their .phy, nothing behind it does, and
+    the process dies with the reference's exception (infer_alns.py:97-117)."""
+    import json
+    from glob import glob
+    from phyloformer_amd.msa_sim import simulate_batch, to_fasta
+    g = json.load(open(os.path.join(repo, "tests/golden/cli_bad_entry.json")))[scenario]
+    ind = tmp_path / "in"
+    ind.mkdir()
+    alns = iter(simulate_batch(8, 5, 12, seed=77))
+    for name in g["listing_order"]:
+        if name == g["offender"]:
+            (ind / name).write_bytes(b"not an alignment\n" if scenario == "bad_extension" else b">s0\nARNDB\n>s1\nARNDC\n")
+        else:
+            (ind / name).write_text(to_fasta(next(alns)))
+    order = [os.path.basename(p) for p in glob(f"{ind}/*")]              # this process's listing order (the CLI's own)
+    want = sorted(os.path.splitext(n)[0] + ".phy" for n in order[:order.index(g["offender"])])
+    r = _run(repo, [os.path.join(repo, "models/pf_base.ckpt"), str(ind), "-o", str(tmp_path / "o")])
+    assert r.returncode != 0
+    assert sorted(os.listdir(tmp_path / "o")) == want
+    last = [ln for ln in r.stderr.strip().splitlines() if ln.strip()][-1]
+    assert last.split(":")[0] == g["exception"] and last == g["last_line"].replace("<in>", str(ind))
+
+
 def test_cli_bucketed_batches_equal_serial_order(repo, tmp_path):
     """All 20 reference test MSAs (4 shapes x 5): the default scheduler (shape buckets, native I/O)
     writes the same files as one-alignment-per-launch with the pure-Python parser/writer, and both
