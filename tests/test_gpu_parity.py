@@ -493,16 +493,20 @@ def test_device_entry_points_survive_out_of_alphabet_bytes(weights, golden):
         e.free(d_out)
 
 
-@pytest.mark.parametrize("ck,n,l,gaps", [("pf", 60, 500, False), ("pf_indel", 200, 500, True)])
+@pytest.mark.parametrize("ck,n,l,gaps", [("pf", 60, 500, False), ("pf_indel", 200, 500, True), ("pf", 200, 2000, False)])
 def test_full_size_properties(engines, ck, n, l, gaps):
-    """BASELINE's full sizes (configs[2] 60 x 500, configs[4] gapped 200 x 500), where the oracle takes minutes, through
+    """BASELINE's full sizes (configs[2] 60 x 500, configs[4] gapped 200 x 500) and the largest alignment the reference's
+    cap admits at configs[3]'s length (200 x 2000: 39.8 M tokens, a 10 GB residual stream), where the oracle takes minutes, through
     properties that do not depend on the size: sites are exchangeable (the distance is a mean over sites of a function
     that is permutation-equivariant along them, model.py:166-187), sequences are equivariant (permuting them permutes
     the distance matrix), an alignment's bits do not depend on its neighbours in the batch, and eight emulated site
     shards (ragged: 500 = 7 x 63 + 59) give the unsharded distances."""
     from phyloformer_amd.phylip import vec_to_matrix
     e = engines(ck)
-    idx = simulate_batch(1, n, l, seed=2025 + n, gaps=gaps)[0]
+    # (the Python simulator is slow for 400,000 residues: the largest case tiles a 200 x 250 alignment along the sites)
+    idx = simulate_batch(1, n, min(l, 250) if n * l > 200_000 else l, seed=2025 + n, gaps=gaps)[0]
+    idx = np.ascontiguousarray(np.tile(idx, (1, l // idx.shape[1])))
+    assert idx.shape == (n, l)
     base = e.forward(idx)
     scale = max(1.0, float(np.abs(base).max()))
     assert np.isfinite(base).all() and (base > 0).all()
