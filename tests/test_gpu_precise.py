@@ -136,7 +136,8 @@ def test_soak_every_accepted_shape_within_the_reference_error(engines, weights):
     within max(1e-4, 2 x |fp32 oracle - fp64 oracle|) of the fp32 oracle - 0 violations.  Uniformly random residues
     (1/3; nothing like an alignment - DESIGN.md section 5): the same bound wherever the shape rule routes to float64, and the
     documented out-of-distribution envelope 2e-4 x max(1, largest distance) on the default kernels.  Every case finite
-    and bit-identical one alignment at a time."""
+    and bit-identical one alignment at a time; every sixth case also through 2-4 emulated site shards (3e-5 of the
+    largest distance)."""
     bad, worst = [], {"default, simulated": 0.0, "default, random residues (relative)": 0.0, "float64 vs fp64 oracle": 0.0}
     try:        # the oracle's BLAS on all 256 hardware threads of the GPU host oversubscribes: 32 is 3 x faster
         from threadpoolctl import threadpool_limits
@@ -165,6 +166,9 @@ def test_soak_every_accepted_shape_within_the_reference_error(engines, weights):
         ok = np.isfinite(got).all() and err <= bound
         if b > 1:
             ok = ok and np.array_equal(np.stack([e.forward(x) for x in idx]), got)
+        if c % 6 == 0 and l >= 2:       # every sixth case also over 2-4 emulated site shards (ragged, sometimes empty)
+            sh = e.forward_shards_emulated(idx, 2 + c % 3)
+            ok = ok and float(np.abs(sh - got).max()) <= 3e-5 * max(1.0, float(np.abs(got).max()))
         if not ok:
             bad.append((c, ck, n, l, b, mode, err, bound))
     print(f"soak: 240 cases, {len(bad)} violations; worst: " + ", ".join(f"{k} {v:.3e}" for k, v in worst.items()))
