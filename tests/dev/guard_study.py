@@ -79,12 +79,9 @@ def gen(out):
     from phyloformer_amd.engine import Engine
     from phyloformer_amd.weights import load_weights
     eng = {n: Engine(load_weights(os.path.join(REPO, "models", n + ".ckpt")), 0) for n in CK}
+    routed = os.environ.get("PF_STUDY_ROUTED") == "1"     # 1: as the product routes (float64 path for small shapes)
     for e in eng.values():
-        e.set_option("precise", 0)
-        try:
-            e.set_option("guard", 0)
-        except Exception:
-            pass
+        e.set_option("precise", -1 if routed else 0)
     res = {}
     t0 = time.time()
     for c, ck, kind, n, l, idx in cases():
