@@ -8,7 +8,9 @@ exception type and the last line of the traceback:
 * ``bad_extension``: a ``.txt`` entry among FASTA files -> ``ValueError`` at that entry (infer_alns.py:100-103),
   every entry listed before it has its ``.phy``;
 * ``bad_residue``: a FASTA file with a byte outside the alphabet -> ``KeyError`` from ``load_alignment``
-  (data.py:26) at that file, files before it written.
+  (data.py:26) at that file, files before it written;
+* ``too_many_seqs``: an alignment of 201 sequences -> ``ValueError`` from ``adaptable_seq2pair`` (model.py:24-28) inside
+  the forward of that file, files before it written.
 
 Output: ``tests/golden/cli_bad_entry.json`` (data only).  ``tests/test_scheduler.py`` and
 ``tests/test_cli_gpu.py`` hold this build's CLI to the same rule: outputs == the entries in front of the offender,
@@ -39,8 +41,10 @@ def main():
     out = {}
     # the listing order is the file system's (glob does not sort): try offender names until one lands strictly
     # inside the listing, so that the fixture shows files on both sides of it
+    big = "".join(f">t{k}\n{'ARN' if k % 2 else 'ARD'}\n" for k in range(201)).encode()      # 201 sequences: over SEQ2PAIR's 200
     todo = [("bad_extension", f"notes{k}.txt", b"not an alignment\n") for k in range(12)] + \
-           [("bad_residue", f"bad{k}.fa", b">s0\nARNDB\n>s1\nARNDC\n") for k in range(12)]
+           [("bad_residue", f"bad{k}.fa", b">s0\nARNDB\n>s1\nARNDC\n") for k in range(12)] + \
+           [("too_many_seqs", f"big{k}.fa", big) for k in range(12)]
     for scenario, offender, content in todo:
         if scenario in out:
             continue

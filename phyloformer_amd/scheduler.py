@@ -59,6 +59,17 @@ def auto_batch(n_seqs: int, n_sites: int, max_batch: int = 4096, token_budget: i
     return int(min(max_batch, max(1, token_budget // tokens)))
 
 
+MAX_SEQS = 200     # SEQ2PAIR = seq2pair(200), /root/reference/phyloformer/model.py:39
+
+
+def too_many_seqs(n_seqs: int) -> Optional[ValueError]:
+    """The reference's forward refuses more than 200 sequences (adaptable_seq2pair, model.py:24-28) when the loop reaches
+    that file; the runner raises the same error at the same place in the order - after the files in front of it."""
+    if n_seqs > MAX_SEQS:
+        return ValueError(f"n_seqs must be smaller or equal to {MAX_SEQS} (or pre-compute a larger global_seq2pair)")
+    return None
+
+
 def has_fasta_ext(alnpath: str) -> bool:
     """Checks if a path ends in .fa or .fasta (infer_alns.py:36-38)."""
     return alnpath.lower().endswith(".fa") or alnpath.lower().endswith(".fasta")
@@ -249,6 +260,11 @@ class DirectoryRunner:
             finally:
                 self.stats["load_wait_s"] += time.perf_counter() - t0
             shape = (int(idx.shape[0]), int(idx.shape[1]))
+            bad = too_many_seqs(shape[0])
+            if bad is not None:
+                for _p, f in inflight:
+                    f.cancel()
+                break
             group = buckets.setdefault(shape, [])
             group.append((path, idx, ids))
             if len(group) >= (self.batch or auto_batch(*shape)):
@@ -278,10 +294,10 @@ class DirectoryRunner:
             t0 = time.perf_counter()
             fb = inflight.popleft().result()
             self.stats["load_wait_s"] += time.perf_counter() - t0
-            ok = (fb.status == 0) & (fb.l > 0)
+            ok = (fb.status == 0) & (fb.l > 0) & (fb.n <= MAX_SEQS)
             stop = len(fb) if ok.all() else int(np.argmin(ok))
             if stop < len(fb):
-                bad = fb.error(stop)
+                bad = fb.error(stop) or too_many_seqs(int(fb.n[stop]))
             ns, ls = fb.n.tolist(), fb.l.tolist()
             for i in range(stop):
                 shape = (ns[i], ls[i])

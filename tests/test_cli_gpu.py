@@ -51,7 +51,7 @@ def test_cli_error_behaviour(repo, tmp_path):
     assert r.returncode != 0 and "TypeError" in r.stderr                            # -o omitted, :53,90
 
 
-@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue"])
+@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue", "too_many_seqs"])
 def test_cli_bad_entry_leaves_what_the_reference_leaves(repo, tmp_path, scenario):
     """The whole CLI on the GPU against the fixture the REAL reference CLI produced (oracle/gen_golden_cli_errors.py):
     the same file names; the entries `glob` lists in front of the offender get their .phy, nothing behind it does, and
@@ -65,7 +65,8 @@ def test_cli_bad_entry_leaves_what_the_reference_leaves(repo, tmp_path, scenario
     alns = iter(simulate_batch(8, 5, 12, seed=77))
     for name in g["listing_order"]:
         if name == g["offender"]:
-            (ind / name).write_bytes(b"not an alignment\n" if scenario == "bad_extension" else b">s0\nARNDB\n>s1\nARNDC\n")
+            (ind / name).write_bytes({"bad_extension": b"not an alignment\n", "bad_residue": b">s0\nARNDB\n>s1\nARNDC\n",
+                                      "too_many_seqs": "".join(f">t{k}\nAR{'N' if k % 2 else 'D'}\n" for k in range(201)).encode()}[scenario])
         else:
             (ind / name).write_text(to_fasta(next(alns)))
     order = [os.path.basename(p) for p in glob(f"{ind}/*")]              # this process's listing order (the CLI's own)

@@ -92,11 +92,12 @@ def test_directory_runner_trees_and_errors(tmp_path):
 
 
 @pytest.mark.parametrize("native_io", [True, False])
-@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue"])
+@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue", "too_many_seqs"])
 def test_bad_entry_side_effects_are_the_references(tmp_path, golden, scenario, native_io):
     """VERDICT r04 / next 7.  The reference handles one directory entry after the other (infer_alns.py:97-117): when it
-    meets an entry without a FASTA extension (ValueError, :100-103) or a file that does not parse (KeyError from
-    load_alignment, data.py:26), every entry listed BEFORE it has its .phy and nothing after it does.  The fixture
+    meets an entry without a FASTA extension (ValueError, :100-103), a file that does not parse (KeyError from
+    load_alignment, data.py:26) or an alignment of more than 200 sequences (ValueError from adaptable_seq2pair inside the
+    forward, model.py:24-28), every entry listed BEFORE it has its .phy and nothing after it does.  The fixture
     (oracle/gen_golden_cli_errors.py) holds what the real CLI left behind; this build's runner, batching and
     prefetching notwithstanding, must leave the same set for the same processing order, and raise the same."""
     g = json.load(open(os.path.join(REPO, "tests", "golden", "cli_bad_entry.json")))[scenario]
@@ -108,7 +109,8 @@ def test_bad_entry_side_effects_are_the_references(tmp_path, golden, scenario, n
     rng = np.random.default_rng(3)
     for name in order:
         if name == offender:
-            (d / name).write_bytes(b"not an alignment\n" if scenario == "bad_extension" else b">s0\nARNDB\n>s1\nARNDC\n")
+            (d / name).write_bytes({"bad_extension": b"not an alignment\n", "bad_residue": b">s0\nARNDB\n>s1\nARNDC\n",
+                                    "too_many_seqs": "".join(f">t{k}\nAR{'N' if k % 2 else 'D'}\n" for k in range(201)).encode()}[scenario])
         else:
             _write_fasta(d / name, rng.integers(0, 20, (5, 12)).astype(np.uint8))
     out = tmp_path / "out"
