@@ -149,12 +149,13 @@ def build(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
         with open(gen, "w") as fh:
             text = json.dumps(info, sort_keys=True)
             fh.write('extern "C" const char* pf_build_info(void) { return R"PFBI(' + text + ')PFBI"; }\n')
-        cmd = [hipcc, *COMMON, "-shared", *objs, gen, "-o", out + ".tmp", "-ldl"]
+        part = f"{out}.{os.getpid()}.tmp"          # (two builders at once - two pytest processes - must not share it)
+        cmd = [hipcc, *COMMON, "-shared", *objs, gen, "-o", part, "-ldl"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             sys.stderr.write(res.stdout + res.stderr)
             raise RuntimeError(f"link failed with exit code {res.returncode}")
-        os.replace(out + ".tmp", out)
+        os.replace(part, out)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out

@@ -250,10 +250,15 @@ void run_pool(int32_t count, int32_t threads, F&& fn) {
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, count));
     if (nt == 1) { for (int32_t i = 0; i < count; ++i) fn(i); return; }
     std::atomic<int32_t> next{0};
+    auto work = [&] { for (int32_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
     std::vector<std::thread> pool;
     pool.reserve(nt);
-    for (int t = 0; t < nt; ++t)
-        pool.emplace_back([&] { for (int32_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); });
+    // the calling thread is one of the workers; a thread the system refuses to start (EAGAIN) only narrows the pool -
+    // nothing may throw across the C ABI
+    for (int t = 1; t < nt; ++t) {
+        try { pool.emplace_back(work); } catch (...) { break; }
+    }
+    work();
     for (auto& th : pool) th.join();
 }
 

@@ -51,6 +51,8 @@ TOKEN_BUDGET = 16 * 1770 * 500
 # files per native load call (FastaBatch): enough to amortise a thread-pool start over many small files, few enough
 # that the first launch does not wait for the whole directory
 FILES_PER_LOAD = 256
+# a partial shape bucket is launched after this many further load calls (bounds what the native pipeline keeps parsed)
+STALE_LOADS = 16
 
 
 def auto_batch(n_seqs: int, n_sites: int, max_batch: int = 4096, token_budget: int = TOKEN_BUDGET) -> int:
@@ -281,9 +283,11 @@ class DirectoryRunner:
         - residues and ids stay in the library until the launch gathers them / the writer formats them."""
         from .hostio import FastaBatch
         buckets: "OrderedDict[Tuple[int, int], list]" = OrderedDict()
+        born: Dict[Tuple[int, int], int] = {}          # load call that opened each partial bucket
         chunks = [paths[k:k + FILES_PER_LOAD] for k in range(0, len(paths), FILES_PER_LOAD)]
         inflight: "deque[Future]" = deque()
         nxt = 0
+        done = 0
         bad: Optional[BaseException] = None
         while not errors and bad is None:
             while nxt < len(chunks) and len(inflight) < 2:
@@ -302,12 +306,20 @@ class DirectoryRunner:
             for i in range(stop):
                 shape = (ns[i], ls[i])
                 group = buckets.get(shape)
-                if group is None:
+                if not group:
                     group = buckets[shape] = []
+                    born[shape] = done
                 group.append((fb.paths[i], (fb, i), None))
                 if len(group) >= (self.batch or auto_batch(*shape)):
                     jobs.put((shape, group))
                     buckets[shape] = []
+            done += 1
+            # A partial bucket keeps its entries' batch objects - every parsed file of those load calls - alive: a rare
+            # shape in a long directory would pin the whole directory in memory.  A bucket that has waited for
+            # STALE_LOADS load calls is launched as it is (an alignment's bits do not depend on its batch).
+            for shape in [sh for sh, g in buckets.items() if g and done - born[sh] >= STALE_LOADS]:
+                jobs.put((shape, buckets[shape]))
+                buckets[shape] = []
         for f in inflight:
             f.cancel()
         for shape, group in sorted(buckets.items(), key=lambda kv: -len(kv[1])):

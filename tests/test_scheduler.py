@@ -273,3 +273,33 @@ def test_cli_site_sharded_dead_rank_ends_the_run_instead_of_hanging(small_dir, t
     assert r.returncode != 0
     assert "rank 1 exited with code 7; terminating the other site-sharded ranks" in r.stderr
     assert time.time() - t0 < 120
+
+
+def test_stale_partial_buckets_are_launched_not_hoarded(tmp_path):
+    """The native pipeline keeps a load call's parsed files alive while any of them waits in a partial shape bucket; a rare
+    shape must not pin a long directory in memory: a bucket that has waited STALE_LOADS load calls is launched as it is.
+    Same outputs as the Python I/O path (an alignment's result does not depend on its batch)."""
+    rng = np.random.default_rng(4)
+    d = tmp_path / "in"
+    d.mkdir()
+    for k in range(60):
+        n, l = (7, 9) if k == 3 else (4, 30)               # one rare shape early in the listing
+        _write_fasta(d / f"y{k:02d}.fa", rng.integers(0, 22, (n, l)).astype(np.uint8))
+    paths = sorted(str(p) for p in d.iterdir())
+    old = (scheduler.FILES_PER_LOAD, scheduler.STALE_LOADS)
+    scheduler.FILES_PER_LOAD, scheduler.STALE_LOADS = 5, 3   # 12 load calls; the rare bucket goes stale after 3
+    try:
+        eng = FakeEngine()
+        out = tmp_path / "o"
+        out.mkdir()
+        scheduler.DirectoryRunner(eng, str(out), batch=1000, io_threads=2).run(paths)
+        rare = [k for k, s_ in enumerate(eng.calls) if s_[1:] == (7, 9)]
+        assert rare and rare[0] < len(eng.calls) - 1, "the rare shape was launched before the end of the directory"
+        assert sum(s_[0] for s_ in eng.calls) == 60 and len(os.listdir(out)) == 60
+        out2 = tmp_path / "o2"
+        out2.mkdir()
+        scheduler.DirectoryRunner(FakeEngine(), str(out2), batch=1000, io_threads=2, native_io=False).run(paths)
+        for f in os.listdir(out):
+            assert (out / f).read_bytes() == (out2 / f).read_bytes()
+    finally:
+        scheduler.FILES_PER_LOAD, scheduler.STALE_LOADS = old
