@@ -841,7 +841,17 @@ def self_launch(args, argv):
                 return max(args.launch_timeout, float(fh.read().strip() or 0))
         except (OSError, ValueError):
             return args.launch_timeout
-    while any(p.poll() is None for p in procs):
+    def exited(p):
+        # Has the supervisor ended?  Asked WITHOUT reaping it (WNOWAIT): the zombie keeps its pid - and, as the session
+        # leader it is, its process-group id - reserved until p.wait() below, so the killpg that follows cannot reach a
+        # stranger's recycled group (poll() reaped, and a reaped pid may be handed out again).
+        if p.returncode is not None:
+            return True
+        try:
+            return os.waitid(os.P_PID, p.pid, os.WEXITED | os.WNOHANG | os.WNOWAIT) is not None
+        except ChildProcessError:
+            return True
+    while not all(exited(p) for p in procs):
         limit = current_limit()
         if time.monotonic() - t_start > limit + 45.0:
             break
@@ -850,15 +860,19 @@ def self_launch(args, argv):
         os.unlink(limit_file)
     except OSError:
         pass
-    late = [p for p in procs if p.poll() is None]
+    late = [p for p in procs if not exited(p)]
     # Every process group started above is signalled, the late ones and those whose supervisor has already left: a
     # supervisor that died on an exception may have left its rank behind, parked in a collective and holding its GPU
-    # (ADVICE r04).  The groups are this launcher's own (start_new_session): nothing else can be in them.
+    # (ADVICE r04).  The groups are this launcher's own (start_new_session) and none of their leaders has been reaped
+    # yet, so the ids still name them.
     for p in procs:
         try:
             os.killpg(p.pid, 15)
         except OSError:
             pass
+    for p in procs:
+        if p not in late:
+            p.wait()
     for p in late:
         try:
             p.wait(timeout=5)

@@ -217,7 +217,8 @@ def run_site_sharded(args, paths, rank, world, out_dir, tqdm):
         bar = tqdm(total=len(paths)) if (tqdm is not None and rank == 0 and not args.worker) else None
         runner = scheduler.SiteShardedRunner(engine, group, rank, world, out_dir, trees=args.trees, batch=args.batch,
                                              io_threads=args.io_threads, native_io=not args.python_io,
-                                             progress=bar.update if bar is not None else None)
+                                             progress=bar.update if bar is not None else None,
+                                             heartbeat_s=(float(os.environ.get("PF_CLI_HEARTBEAT", "5")) if args.worker else None))
         try:
             stats = runner.run(paths)
         finally:

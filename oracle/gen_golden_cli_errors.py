@@ -10,7 +10,12 @@ exception type and the last line of the traceback:
 * ``bad_residue``: a FASTA file with a byte outside the alphabet -> ``KeyError`` from ``load_alignment``
   (data.py:26) at that file, files before it written;
 * ``too_many_seqs``: an alignment of 201 sequences -> ``ValueError`` from ``adaptable_seq2pair`` (model.py:24-28) inside
-  the forward of that file, files before it written.
+  the forward of that file, files before it written;
+* ``single_sequence``: an alignment of ONE sequence parses (``fasta_edge.json``) and then fails inside the forward with a
+  ``RuntimeError`` - there are no pairs, and ``attention.py:193`` cannot view the empty tensor - files before it written.
+
+Scenarios already in the fixture are kept as they are (the listing order is the file system's); delete the file to
+regenerate all of them.
 
 Output: ``tests/golden/cli_bad_entry.json`` (data only).  ``tests/test_scheduler.py`` and
 ``tests/test_cli_gpu.py`` hold this build's CLI to the same rule: outputs == the entries in front of the offender,
@@ -38,13 +43,15 @@ def main():
     env = dict(os.environ, PYTHONPATH=f"{stub}:{REF}")
     alns = simulate_batch(6, 5, 12, seed=77)
     names = ["c.fa", "a.fasta", "e.FA", "b.fa", "f.fa", "d.fa"]
-    out = {}
+    path = os.path.join(REPO, "tests", "golden", "cli_bad_entry.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
     # the listing order is the file system's (glob does not sort): try offender names until one lands strictly
     # inside the listing, so that the fixture shows files on both sides of it
     big = "".join(f">t{k}\n{'ARN' if k % 2 else 'ARD'}\n" for k in range(201)).encode()      # 201 sequences: over SEQ2PAIR's 200
     todo = [("bad_extension", f"notes{k}.txt", b"not an alignment\n") for k in range(12)] + \
            [("bad_residue", f"bad{k}.fa", b">s0\nARNDB\n>s1\nARNDC\n") for k in range(12)] + \
-           [("too_many_seqs", f"big{k}.fa", big) for k in range(12)]
+           [("too_many_seqs", f"big{k}.fa", big) for k in range(12)] + \
+           [("single_sequence", f"one{k}.fa", b">s0\nARNDCQEGHILK\n") for k in range(12)]
     for scenario, offender, content in todo:
         if scenario in out:
             continue
@@ -70,7 +77,7 @@ def main():
                              "outputs": written, "exception": last.split(":")[0],
                              "last_line": last.replace(ind, "<in>")}
             print(scenario, order, "->", written, "|", last.replace(ind, "<in>"))
-    with open(os.path.join(REPO, "tests", "golden", "cli_bad_entry.json"), "w") as fh:
+    with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
 
 

@@ -35,11 +35,13 @@ ARCH = "gfx950"
 # ahead of the MFMAs and is 1.3 % faster on the forward (k_colstats gains too).
 SCHED = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-# source -> extra flags.  pf_precise.hip (float64 kernels) is its own translation unit with the default
-# strategy: iterative-ilp crashes hipcc's register allocator on it (ROCm 7.2, kp_head).
+# source -> extra flags.  pf_precise.hip (float64 kernels) and pf_mha.hip (softmax attention operator) are their own
+# translation units with the default strategy: iterative-ilp crashes hipcc's register allocator on them (ROCm 7.2,
+# kp_head / k_mha_qkv).
 UNITS: Dict[str, List[str]] = {
     "pf_lib.hip": [f"--offload-arch={ARCH}", "-fno-slp-vectorize"] + SCHED,
     "pf_precise.hip": [f"--offload-arch={ARCH}"],
+    "pf_mha.hip": [f"--offload-arch={ARCH}", "-fno-slp-vectorize"],
     "pf_hostio.cpp": [],
 }
 HEADERS = ["pf_device.hip.h", "pf_mha.hip.h", "pf_precise.hip.h", "pf_precise_host.hip.h", "pf_layout.h", "pf_host_prep.h"]
@@ -98,24 +100,26 @@ def _hipcc_version(hipcc: str) -> str:
     return f"HIP {hip}; {clang}"[:200]
 
 
-def build(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = LIB, extra: Optional[List[str]] = None) -> str:
     """Compile and link.  ``PF_ALLOW_SCHED_FALLBACK=1`` lets a hipcc that cannot compile pf_lib.hip with the
     iterative-ILP strategy fall back to the default one (1-7 % slower kernels) - the library
     then reports ``sched_fallback: true`` and bench.py carries it; without the variable the build FAILS.
     ``PF_BUILD_FORCE_FALLBACK=1`` (tests) takes the fallback without trying."""
     if not force and not is_stale(out):
         return out
+    extra = list(extra or [])            # A/B builds (tools/build_variant.py): -D switches for the HIP units
     hipcc = hipcc_path()
     allow = os.environ.get("PF_ALLOW_SCHED_FALLBACK") == "1"
     forced = os.environ.get("PF_BUILD_FORCE_FALLBACK") == "1"
     tmp = tempfile.mkdtemp(prefix="pf_build_")
     try:
         objs, used = [], {}
-        for unit, extra in UNITS.items():
-            attempts = [extra]
+        for unit, unit_flags in UNITS.items():
+            uf = unit_flags + (extra if unit.endswith(".hip") else [])
+            attempts = [uf]
             if unit == "pf_lib.hip":
-                no_sched = [f for f in extra if f not in SCHED]
-                attempts = [no_sched] if forced else ([extra, no_sched] if allow else [extra])
+                no_sched = [f for f in uf if f not in SCHED]
+                attempts = [no_sched] if forced else ([uf, no_sched] if allow else [uf])
             obj = os.path.join(tmp, unit + ".o")
             res = None
             for flags in attempts:

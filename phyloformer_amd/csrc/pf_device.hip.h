@@ -17,10 +17,10 @@
 //               Z[l][h][c] = sum_p k'[p,l,h] x~[p,l,c]          (V projection pulled out of the sum)
 // so the only per-token dense contractions left are the FFN (64->256->64), the
 // column out-projection and the next block's row V/q/k projection: those run
-// on MFMA as split-bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate).
+// on MFMA as split-fp16 (hi*hi + lo*hi + hi*lo, fp32 accumulate; bf16 in rounds 1-5, PF_F16 below).
 //
 // MFMA tiling ("token tile" = 32 consecutive sites of one pair, one wave):
-//   v_mfma_f32_32x32x16_bf16, tokens on the N side.  Lane l = (t = l & 31, h = l >> 5)
+//   v_mfma_f32_32x32x16_f16, tokens on the N side.  Lane l = (t = l & 31, h = l >> 5)
 //   owns, for token t, the 32 channels kmap(j, h) = 8*(j>>2) + 4*h + (j&3), j = 0..31.
 //   This is at once the B-operand layout (8 consecutive j per K-step), the C/D
 //   layout of a 32-row output tile (row = (r&3) + 8*(r>>2) + 4*h) and a 16-byte
@@ -37,10 +37,41 @@ namespace pfk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The 16-bit format of the split MFMA operands (x ~= hi + lo, products hi*hi + hi*lo + lo*hi in fp32):
+//   PF_F16 = 1 (round 6, default): IEEE half.  Two limbs carry 22 significant bits (2^-22 relative; below 2^-3 the lo
+//              limb is subnormal and the error an absolute 2^-25 - the matrix cores, v_cvt_pk_f16_f32 and
+//              v_dot2c_f32_f16 all keep fp16 subnormals, tools/f16_probe.hip), i.e. fp32's own rounding level, at the
+//              bf16 MFMA rate.  Range: |operand| < 65504 - guaranteed by construction, see "fp16 operand ranges" below.
+//   PF_F16 = 0 (rounds 1-5, kept for A/B builds: tools/build_variant.py lib.so -DPF_F16=0): bfloat16, 16 bits in two
+//              limbs (2^-17 relative), fp32's exponent range.
+// (the switch itself lives in pf_layout.h: the host-side packing must agree)
+#if PF_F16
+typedef _Float16 h16_t;
+#define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define PF_DOT2C "v_dot2c_f32_f16"
+#define PF_NEG1_LO 0x0000bc00u      // (-1, 0) and (0, -1) as packed pairs of the format
+#define PF_NEG1_HI 0xbc000000u
+#else
+typedef __bf16 h16_t;
+#define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define PF_DOT2C "v_dot2c_f32_bf16"
+#define PF_NEG1_LO 0x0000bf80u
+#define PF_NEG1_HI 0xbf800000u
+#endif
+typedef h16_t frag_t __attribute__((ext_vector_type(8)));      // one MFMA operand fragment: 8 K-values of a lane
+typedef h16_t h16x2 __attribute__((ext_vector_type(2)));
+// fp16 operand ranges (PF_F16): an operand that overflows to inf poisons a whole tile, so every split operand is
+// bounded by construction - x~ (LayerNorm output) by sqrt(63); the FFN hidden activation and the row-mix base
+// matrix by the checkpoint's weights (checked at pf_create, pf_lib.hip::check_f16_ranges: a checkpoint outside the
+// range runs on the float64 kernels); the two data-dependent factors 1 / mean(q') are applied on the side where
+// they meet q' itself, so that only q' / mean(q') <= (number of elements) is ever converted:
+//   row mix:     A = M_base[h][c] * ROWMIX_A_SCALE (k_rowfin),  B = q'[l][h] * L / S_q[h] * ROWMIX_B_SCALE (k_main);
+//   column apply: A = Wo * 2^4 (host),  B = q'_c[p][h] * ctx[l][hd] * 2^-4  (<= P * max|v| / 16 < 65504 for P <= 19,900).
+constexpr float COLAPPLY_B_SCALE = PF_F16 ? 0.0625f : 1.f;     // 2^-4 on q' (x) ctx; Wo carries 2^4 (pf_lib.hip)
+constexpr float COLAPPLY_A_SCALE = PF_F16 ? 16.f : 1.f;
 // explicit LDS pointers: with an opaque per-lane base (PF_OPAQUE) every fragment / constant read
 // becomes `ds_read_b128 v, base offset:imm` instead of a v_add_u32 with a > 16-bit literal per read
-typedef const bf16x8 __attribute__((address_space(3)))* lds_frag_t;
+typedef const frag_t __attribute__((address_space(3)))* lds_frag_t;
 typedef const float __attribute__((address_space(3)))* lds_f32_t;
 #define PF_OPAQUE(p) asm volatile("" : "+v"(p))
 
@@ -191,13 +222,12 @@ __device__ __forceinline__ float gelu_as(float x) {
 __device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// FFN hidden activation for two accumulator values at once, fused with the bf16 hi/lo split.
+// FFN hidden activation for two accumulator values at once, fused with the 16-bit hi/lo split.
 // The FFN weights are pre-scaled on the host so that the accumulator holds a*h with
 // a^2 = log2(e)/2 (the variable the activation polynomial below is fitted in) and W2 carries 1/a;
-// the function returns 2*a*gelu(h) as packed bf16 pairs (W2 carries 1/(2a)):  hi = bf16(g), lo = bf16(g - hi).
+// the function returns 2*a*gelu(h) as packed 16-bit pairs (W2 carries 1/(2a)):  hi = h16(g), lo = h16(g - hi).
 // Scalar VOP3 forms with free |x| / -x modifiers; built with -fno-slp-vectorize so that hipcc does
 // not re-pack them into v_pk_* (see gelu_scaled).
 constexpr float GELU_ALPHA = 0.84932180028801904272f;   // sqrt(log2(e) / 2)
@@ -219,14 +249,15 @@ __device__ __forceinline__ float gelu_scaled(float x) {
     p = fmaf(p, u, -0.00003762f);                       // log2(2 Q): constant term of log2 Q plus one
     return fmaf(u, 1.f - __builtin_amdgcn_exp2f(p), x);
 }
-// (g0, g1) -> packed bf16 pairs hi = bf16(g), lo = bf16(g - hi).  The residual g - hi comes from
-// v_dot2c_f32_bf16 (g += hi.lo * -1 + hi.hi * 0): one 4.5-cycle op instead of unpack (4.2) + subtract
-// (2.9), bit-identical to the fp32 subtraction (tools/dot2c_test.hip), and it overlaps with MFMA.
+// (g0, g1) -> packed 16-bit pairs hi = h16(g), lo = h16(g - hi).  The residual g - hi comes from
+// v_dot2c_f32_{f16,bf16} (g += hi.lo * -1 + hi.hi * 0): one 4.5-cycle op instead of unpack (4.2) + subtract
+// (2.9), bit-identical to the fp32 subtraction (tools/dot2c_test.hip, tools/f16_probe.hip - subnormal hi
+// included), and it overlaps with MFMA.
 __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out, unsigned& lo_out) {
-    const bf16x2 h2 = {(__bf16)g0, (__bf16)g1};
+    const h16x2 h2 = {(h16_t)g0, (h16_t)g1};
     const unsigned hb = __builtin_bit_cast(unsigned, h2);
     float r0 = g0, r1 = g1;
-    // HAZARD (measured on gfx950, not interlocked): a VALU that reads the result of v_dot2c_f32_bf16
+    // HAZARD (measured on gfx950, not interlocked): a VALU that reads the result of v_dot2c_f32_*
     // needs >= 2 wait states after it (s_nop 0 gives wrong data, s_nop 1 is clean on every golden);
     // hipcc pads nothing inside an asm statement, so the pad lives in the string, with one spare state.
 #ifndef PF_DOT2C_PRE
@@ -234,26 +265,26 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
 #define PF_DOT2C_POST "\n\ts_nop 2"
 #endif
 #ifdef PF_SPLIT_NODOT
-    // same residual through plain VALU (shift / mask / subtract): two more instructions per pair, but
+    // same residual through plain VALU (unpack / subtract): two more instructions per pair, but
     // unlike v_dot2c (matrix-side datapath) they can issue in the shadow of another wave's MFMA
-    r0 = g0 - __builtin_bit_cast(float, hb << 16);
-    r1 = g1 - __builtin_bit_cast(float, hb & 0xffff0000u);
+    r0 = g0 - (float)h2[0];
+    r1 = g1 - (float)h2[1];
 #else
-    asm(PF_DOT2C_PRE "v_dot2c_f32_bf16 %0, %2, %4\n\tv_dot2c_f32_bf16 %1, %3, %4" PF_DOT2C_POST
-                 : "+v"(r0), "+v"(r1) : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(hb));
+    asm(PF_DOT2C_PRE PF_DOT2C " %0, %2, %4\n\t" PF_DOT2C " %1, %3, %4" PF_DOT2C_POST
+                 : "+v"(r0), "+v"(r1) : "s"(PF_NEG1_LO), "s"(PF_NEG1_HI), "v"(hb));
 #endif
-    const bf16x2 l2 = {(__bf16)r0, (__bf16)r1};
+    const h16x2 l2 = {(h16_t)r0, (h16_t)r1};
     hi_out = hb;
     lo_out = __builtin_bit_cast(unsigned, l2);
 }
 __device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {   // tools/
     split_pair(gelu_scaled(x0), gelu_scaled(x1), hi_out, lo_out);
 }
-// split 8 floats into bf16 hi + bf16 lo fragments (x ~= hi + lo to 2^-17 relative).  The eight
+// split 8 floats into hi + lo fragments (x ~= hi + lo to 2^-22 relative in fp16, 2^-17 in bf16).  The eight
 // v_dot2c residuals are issued back to back in one asm block: each then sits >= 2 instructions ahead of
 // the first reader of its result, and a single s_nop covers the last one - instead of one pad per
 // pair as in split_pair (the pads alone were ~3 % of k_main's issue slots).
-__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void split8(const float* v, frag_t& hi, frag_t& lo) {
 #ifdef PF_SPLIT_NODOT
     u32x4 h, l;
 #pragma unroll
@@ -263,44 +294,43 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
         h[k] = a;
         l[k] = b;
     }
-    hi = __builtin_bit_cast(bf16x8, h);
-    lo = __builtin_bit_cast(bf16x8, l);
+    hi = __builtin_bit_cast(frag_t, h);
+    lo = __builtin_bit_cast(frag_t, l);
 #else
     u32x4 h, l;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bf16x2 h2 = {(__bf16)v[2 * k], (__bf16)v[2 * k + 1]};
+        const h16x2 h2 = {(h16_t)v[2 * k], (h16_t)v[2 * k + 1]};
         h[k] = __builtin_bit_cast(unsigned, h2);
     }
     float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7];
     // not volatile: a pure function of its operands, so the scheduler may interleave the splits of
     // independent splits instead of keeping every asm statement in program order
     asm(
-        "v_dot2c_f32_bf16 %0, %8, %10\n\tv_dot2c_f32_bf16 %1, %9, %10\n\t"
-        "v_dot2c_f32_bf16 %2, %8, %11\n\tv_dot2c_f32_bf16 %3, %9, %11\n\t"
-        "v_dot2c_f32_bf16 %4, %8, %12\n\tv_dot2c_f32_bf16 %5, %9, %12\n\t"
-        "v_dot2c_f32_bf16 %6, %8, %13\n\tv_dot2c_f32_bf16 %7, %9, %13\n\ts_nop 1"
+        PF_DOT2C " %0, %8, %10\n\t" PF_DOT2C " %1, %9, %10\n\t"
+        PF_DOT2C " %2, %8, %11\n\t" PF_DOT2C " %3, %9, %11\n\t"
+        PF_DOT2C " %4, %8, %12\n\t" PF_DOT2C " %5, %9, %12\n\t"
+        PF_DOT2C " %6, %8, %13\n\t" PF_DOT2C " %7, %9, %13\n\ts_nop 1"
         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
-        : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
-    const bf16x2 l0 = {(__bf16)r0, (__bf16)r1}, l1 = {(__bf16)r2, (__bf16)r3}, l2 = {(__bf16)r4, (__bf16)r5},
-                 l3 = {(__bf16)r6, (__bf16)r7};
+        : "s"(PF_NEG1_LO), "s"(PF_NEG1_HI), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    const h16x2 l0 = {(h16_t)r0, (h16_t)r1}, l1 = {(h16_t)r2, (h16_t)r3}, l2 = {(h16_t)r4, (h16_t)r5},
+                 l3 = {(h16_t)r6, (h16_t)r7};
     l[0] = __builtin_bit_cast(unsigned, l0);
     l[1] = __builtin_bit_cast(unsigned, l1);
     l[2] = __builtin_bit_cast(unsigned, l2);
     l[3] = __builtin_bit_cast(unsigned, l3);
-    hi = __builtin_bit_cast(bf16x8, h);
-    lo = __builtin_bit_cast(bf16x8, l);
+    hi = __builtin_bit_cast(frag_t, h);
+    lo = __builtin_bit_cast(frag_t, l);
 #endif
 }
 // eight accumulator values acc[base .. base+7] -> GELU -> one B-operand fragment pair
-__device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, frag_t& hi, frag_t& lo) {
     float g[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) g[k] = gelu_scaled(acc[base + k]);
     split8(g, hi, lo);
 }
 
-#define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // acc += (a_hi + a_lo) * (b_hi + b_lo) without the lo*lo term.
 // Pass order: consecutive MFMAs share one operand - (hi,lo) (hi,hi) (lo,hi): A changes once, B changes once -
@@ -308,8 +338,8 @@ __device__ __forceinline__ void gelu_split8(const f32x16& acc, int base, bf16x8&
 // also share it across the seam: ... (lo,hi) | (lo',hi) (hi',hi) (hi',lo).  Fewer operand switches between
 // consecutive MFMAs measurably lower the power the matrix pipe draws: -1.0 % launch time against the
 // (lo,hi) (hi,lo) (hi,hi) order of round 1 (A/B in one GPU call, tools/flag_compare.py).
-__device__ __forceinline__ void mfma3(f32x16& acc, const bf16x8& a_hi, const bf16x8& a_lo,
-                                      const bf16x8& b_hi, const bf16x8& b_lo, const bool flip = false) {
+__device__ __forceinline__ void mfma3(f32x16& acc, const frag_t& a_hi, const frag_t& a_lo,
+                                      const frag_t& b_hi, const frag_t& b_lo, const bool flip = false) {
     if (!flip) {
         acc = PF_MFMA(a_hi, b_lo, acc);
         acc = PF_MFMA(a_hi, b_hi, acc);
@@ -323,8 +353,8 @@ __device__ __forceinline__ void mfma3(f32x16& acc, const bf16x8& a_hi, const bf1
 
 // first product of a chain: C is the inline constant 0 of the MFMA encoding, so the accumulator needs no
 // sixteen v_mov to be cleared
-__device__ __forceinline__ void mfma3_zero(f32x16& acc, const bf16x8& a_hi, const bf16x8& a_lo,
-                                           const bf16x8& b_hi, const bf16x8& b_lo, const bool flip = false) {
+__device__ __forceinline__ void mfma3_zero(f32x16& acc, const frag_t& a_hi, const frag_t& a_lo,
+                                           const frag_t& b_hi, const frag_t& b_lo, const bool flip = false) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!flip) {
         acc = PF_MFMA(a_hi, b_lo, z);
@@ -358,35 +388,6 @@ __device__ __forceinline__ void ln_pair(const float (&x)[32], float (&xn)[32]) {
     for (int j = 0; j < 32; ++j) xn[j] *= rstd;
 }
 
-struct MainArgs {
-    float* x;               // [B][P][Lloc][64] in/out
-    float* qrow;            // [B][P][Lloc][4]  in: q' of this block's row attn; out: next block's
-    const float* qcol;      // [B][P][Lloc][4]
-    const bf16x8* mfrag;    // [B][P][2 To][2 hi/lo][32] row mix M^T (+bias row) as MFMA A fragments
-    const float* ctx;       // [B][Lloc][64]
-    float* spart;           // [B][P][ntiles][72]  out: per-tile statistics of the next block's row attn
-    float* outpart;         // [B][P][ntiles]      out (last block): per-tile sum_l softplus
-    const bf16x8* wimg;     // LDS image (FRAG_END fragments) in global memory
-    const float* consts;    // CONST_LEN floats
-    const bf16x8* wv_lo;    // [2 T][4 s][64] lo fragments of the next row attn's Wv' (global, L1/L2)
-    const float* table;     // [22][64] relu(W_emb + b_emb)          (MODE_FIRST)
-    const uint8_t* idx;     // [B][N][Lloc]                           (MODE_FIRST)
-    const int16_t* pair_i;  // [P]                                    (MODE_FIRST)
-    const int16_t* pair_j;  // [P]
-    int B, N, P, Lloc;
-    int flat;               // tiling (tile_plan() on the host): 0 = every pair row has its own ceil(L / 32) tiles,
-                            // 1 = the P * L tokens of an alignment are cut into tiles of 32 consecutive tokens
-    int nt_aln;             // tiles per alignment
-    int slots_aln;          // per-tile partial slots per alignment (spart / outpart): nt_aln, + P when flat
-    size_t trash_tok;       // token index of a 32-token scratch area behind x and qrow (masked lanes)
-    int store_x_last;       // debug: MODE_LAST also writes x back
-    unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
-    int ablate;             // perf experiments only (results invalid): 1 no x load, 2 no stores,
-                            // 4 no next-row phase, 8 no apply phase, 16 no FFN (2 is unused now)
-};
-
-enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_MID0 = 3 };
-
 typedef const f32x4 __attribute__((address_space(3)))* lds_f32x4_t;
 __device__ __forceinline__ void load_acc_bias(f32x16& acc, lds_f32_t lds_bias_h) {
     // acc[r] = bias[row(r, h)], row = 8*(r>>2) + 4*h + (r&3): four 16-byte LDS reads; the caller
@@ -408,12 +409,43 @@ __device__ __forceinline__ void load_acc_bias(f32x16& acc, const float* lds_bias
     }
 }
 
-__device__ __forceinline__ bf16x8 zero_frag() {
-    bf16x8 z;
+__device__ __forceinline__ frag_t zero_frag() {
+    frag_t z;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+    for (int i = 0; i < 8; ++i) z[i] = (h16_t)0.f;
     return z;
 }
+
+#ifndef PF_DEVICE_HELPERS_ONLY      // (pf_mha.hip takes the helpers above and none of the kernels below)
+struct MainArgs {
+    float* x;               // [B][P][Lloc][64] in/out
+    float* qrow;            // [B][P][Lloc][4]  in: q' of this block's row attn; out: next block's
+    const float* qcol;      // [B][P][Lloc][4]
+    const frag_t* mfrag;    // [B][P][2 To][2 hi/lo][32] row mix base M_base^T (+bias rows) as MFMA A fragments
+    const float* rq;        // [B][P][4] L / S_q[h] (* RowFinArgs::b_scale): the factor that turns q' into q' / mean(q')
+    const float* ctx;       // [B][Lloc][64]
+    float* spart;           // [B][P][ntiles][72]  out: per-tile statistics of the next block's row attn
+    float* outpart;         // [B][P][ntiles]      out (last block): per-tile sum_l softplus
+    const frag_t* wimg;     // LDS image (FRAG_END fragments) in global memory
+    const float* consts;    // CONST_LEN floats
+    const frag_t* wv_lo;    // [2 T][4 s][64] lo fragments of the next row attn's Wv' (global, L1/L2)
+    const float* table;     // [22][64] relu(W_emb + b_emb)          (MODE_FIRST)
+    const uint8_t* idx;     // [B][N][Lloc]                           (MODE_FIRST)
+    const int16_t* pair_i;  // [P]                                    (MODE_FIRST)
+    const int16_t* pair_j;  // [P]
+    int B, N, P, Lloc;
+    int flat;               // tiling (tile_plan() on the host): 0 = every pair row has its own ceil(L / 32) tiles,
+                            // 1 = the P * L tokens of an alignment are cut into tiles of 32 consecutive tokens
+    int nt_aln;             // tiles per alignment
+    int slots_aln;          // per-tile partial slots per alignment (spart / outpart): nt_aln, + P when flat
+    size_t trash_tok;       // token index of a 32-token scratch area behind x and qrow (masked lanes)
+    int store_x_last;       // debug: MODE_LAST also writes x back
+    unsigned long long* prof;   // optional: per-phase cycle totals [8] (s_memtime), perf experiments
+    int ablate;             // perf experiments only (results invalid): 1 no x load, 2 no stores,
+                            // 4 no next-row phase, 8 no apply phase, 16 no FFN (2 is unused now)
+};
+
+enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_MID0 = 3 };
 
 // Two tilings of an alignment's P x L tokens into work items of 32 tokens share the kernel:
 //   row tiling  (flat = 0): every pair row is cut into ceil(L / 32) tiles of its own; the last tile of a row is
@@ -505,7 +537,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         constexpr int lo = (MODE == MODE_FIRST) ? FRAG_WV : 0;
         constexpr int hi = (MODE == MODE_LAST) ? FRAG_WV : FRAG_END;
         static_assert(lo % 64 == 0 && hi % 64 == 0 && FRAG_END % 64 == 0, "the image is copied in whole waves");
-        const bf16x8* src = a.wimg;
+        const frag_t* src = a.wimg;
         const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
         const float cv = a.consts[min((int)threadIdx.x, CONST_LEN - 1)];
 #pragma unroll
@@ -557,7 +589,8 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
         const int task0 = run0, task1 = ntasks;
         TilePos cur = tile_pos<FLAT>(a, min(task0, ntasks - 1), ntiles);
         int frag_row = -1;                          // the row (b * P + p) whose row-mix fragments are in mfr
-        bf16x8 mfr[4];
+        frag_t mfr[4];
+        f32x4 rqv = {0.f, 0.f, 0.f, 0.f};          // L / S_q[h] of that row (wave-uniform)
         // The next tile's residual rows and q' are requested when the FFN of the current tile starts
         // (the residual lives in the GEMM2 accumulators from then on, see below) and land during
         // its ~6 us of matrix work, so a tile never starts by waiting on HBM.
@@ -609,9 +642,14 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             int ai = 0, aj = 0;
             if (MODE == MODE_FIRST) { const int pp = cur.r0 + (lp.in_r1 ? 1 : 0); ai = a.pair_i[pp]; aj = a.pair_j[pp]; }
             auto load_mfr = [&](int r) {
-                const bf16x8* mf = a.mfrag + (size_t)r * 128 + t;
+                const frag_t* mf = a.mfrag + (size_t)r * 128 + t;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) mfr[q] = mf[q * 32];
+                // (the row is wave-uniform: read through the constant address space, i.e. one s_load_dwordx4 into SGPRs -
+                // as a vector load the four values cost four VGPRs across the whole tile loop, which k_main does not have;
+                // rq was written by the previous launch, so the scalar cache cannot hold a stale line)
+                typedef const f32x4 __attribute__((address_space(4)))* const_f32x4_t;
+                rqv = *(const_f32x4_t)(unsigned long long)(a.rq + (size_t)__builtin_amdgcn_readfirstlane(r) * 4);
                 frag_row = r;
             };
             // the pair's row-mix fragments are loaded once per row, not once per tile
@@ -668,10 +706,10 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         auto mix = [&](const bool mine) {
                             float v[8];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = mine ? qr[i] : 0.f;
+                            for (int i = 0; i < 4; ++i) v[i] = mine ? qr[i] * rqv[i] : 0.f;     // q' / mean(q') <= L
                             v[4] = v[5] = mine ? 1.f : 0.f;   // K slot 4: row out_proj bias, slot 5: column's
                             v[6] = v[7] = 0.f;
-                            bf16x8 qb_hi, qb_lo;
+                            frag_t qb_hi, qb_lo;
                             split8(v, qb_hi, qb_lo);
                             // lanes h = 1 carry K = 8..15, which the B operand zeroes: any finite A will do, so
                             // they hold their partner's fragment instead of a masked load
@@ -686,7 +724,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     }
                     // ---- column attention apply: o[hd] = q'_c[h] * ctx[site][hd];  y += Wo_c o
                     {
-                        const f32x4 qc = pqc;
+                        const f32x4 qc = pqc * COLAPPLY_B_SCALE;     // (Wo carries the inverse, see "fp16 operand ranges")
                         float o[32];
 #pragma unroll
                         for (int g = 0; g < 8; ++g) {
@@ -696,12 +734,12 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         }
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            bf16x8 ob_hi, ob_lo;
+                            frag_t ob_hi, ob_lo;
                             split8(&o[8 * s], ob_hi, ob_lo);
 #pragma unroll
                             for (int To = 0; To < 2; ++To) {
                                 lds_frag_t f = wop + ((To * 4 + s) * 2) * 64;
-                                const bf16x8 a_hi = f[0], a_lo = f[64];
+                                const frag_t a_hi = f[0], a_lo = f[64];
                                 mfma3(ya[To], a_hi, a_lo, ob_hi, ob_lo, To == 1);
                             }
                         }
@@ -713,7 +751,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 PF_TICK(1);
                 // ---- feed-forward (model.py:101-104): x += W2 gelu(W1' x~ + b1') + b2
                 if (!(a.ablate & 16)) {
-                    bf16x8 xb_hi[4], xb_lo[4];
+                    frag_t xb_hi[4], xb_lo[4];
                     {
                         float xn[32];
                         ln_pair(x, xn);
@@ -739,23 +777,23 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                         load_acc_bias(ha, bp);
                         // software-pipelined fragment reads: the next step's A operands are in
                         // flight while the current step's three MFMAs issue
-                        bf16x8 fh = f1[0], fl = f1[64];
+                        frag_t fh = f1[0], fl = f1[64];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            bf16x8 nh, nl;
+                            frag_t nh, nl;
                             if (s < 3) { nh = f1[(s + 1) * 128]; nl = f1[(s + 1) * 128 + 64]; }
                             else { nh = f2[0]; nl = f2[64]; }
                             mfma3(ha, fh, fl, xb_hi[s], xb_lo[s]);
                             fh = nh; fl = nl;
                         }
-                        bf16x8 g_hi[2], g_lo[2];
+                        frag_t g_hi[2], g_lo[2];
                         gelu_split8(ha, 0, g_hi[0], g_lo[0]);
                         gelu_split8(ha, 8, g_hi[1], g_lo[1]);
                         // GEMM2 steps in (u, To) order; fragment (To, 2T+u) lives at f2[(To*32 + u*2)*64]
 #pragma unroll
                         for (int st = 0; st < 4; ++st) {
                             const int u = st >> 1, To = st & 1;
-                            bf16x8 nh = fh, nl = fl;
+                            frag_t nh = fh, nl = fl;
                             if (st < 3) {
                                 const int nu = (st + 1) >> 1, nTo = (st + 1) & 1;
                                 nh = f2[(nTo * 32 + nu * 2) * 64];
@@ -774,7 +812,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             if (MODE != MODE_LAST && !(a.ablate & 4)) {
                 // ---- statistics of the next block's row attention (attention.py:163-190)
                 // Wv' lo fragments (L2) are requested before the residual store for the same reason
-                bf16x8 wl[8];
+                frag_t wl[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) wl[i] = a.wv_lo[i * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0);
@@ -795,7 +833,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                 {
                     float xn[32];
                     ln_pair(x, xn);
-                    bf16x8 xb_hi[4], xb_lo[4];
+                    frag_t xb_hi[4], xb_lo[4];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) split8(&xn[8 * s], xb_hi[s], xb_lo[s]);
                     // q/k rows first (operands in LDS): the Wv' lo fragments requested above get the
@@ -803,7 +841,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         // output rows >= 8 are never read: lanes t >= 8 reuse rows t & 7 (finite) unmasked
-                        const bf16x8 q_hi = qkp[(s * 2) * 16], q_lo = qkp[(s * 2 + 1) * 16];
+                        const frag_t q_hi = qkp[(s * 2) * 16], q_lo = qkp[(s * 2 + 1) * 16];
                         if (s == 0) mfma3_zero(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
                         else mfma3(va[2], q_hi, q_lo, xb_hi[s], xb_lo[s]);
                     }
@@ -811,7 +849,7 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int T = 0; T < 2; ++T) {
-                            const bf16x8 f_hi = wvp[(T * 4 + s) * 64];
+                            const frag_t f_hi = wvp[(T * 4 + s) * 64];
                             if (s == 0) mfma3_zero(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s], T == 1);
                             else mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s], T == 1);
                         }
@@ -1022,10 +1060,11 @@ __global__ void __launch_bounds__(EMBED_THREADS) k_embed(EmbedArgs a) {
 struct RowFinArgs {
     const float* srow;   // [B*P][nparts][72]  statistics, as nparts partial sums per pair (k_main: one per
                          //                    tile; k_embed / all-reduced: nparts = 1)
-    float* mrow;         // [B*P][4][64]   fp32 M[h][c] (k_colstats, debug tap)
-    bf16x8* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments of M^T: K slots 0-3 heads, 4 the row
-                         //                    out_proj bias, 5 the column out_proj bias (k_main sets both B
-                         //                    slots to 1, k_colstats only slot 4)
+    float* mrow;         // [B*P][4][64]   fp32 M[h][c] = M_base[h][c] * L / S_q[h] (k_colstats, debug tap)
+    frag_t* mfrag;       // [B*P][2 To][2 hi/lo][32]  MFMA A fragments of M_base^T * a_scale: K slots 0-3 heads (WITHOUT
+                         //                    the factor L / S_q[h], which k_main applies to q' - rq below - so that no
+                         //                    1 / mean(q') ever has to fit the 16-bit format), 4 the row out_proj bias,
+                         //                    5 the column out_proj bias (k_main sets both B slots to 1)
     const float* woT;    // [64 hd][64 c]  row out_proj, transposed
     const float* bv;     // [64] folded row v bias
     const float* bias;   // [64] row out_proj bias
@@ -1034,6 +1073,9 @@ struct RowFinArgs {
     float L_total;
     int flat, P, Lloc, slots_aln;   // where a pair's partials are (part_range): nparts each, or k_main's flat tiling
     int iters;           // groups of four pairs per block
+    float* rq;           // [B*P][4]  L / S_q[h] * b_scale
+    float a_scale, b_scale;   // powers of two, a_scale * b_scale = 1: b_scale < 1 only when L_total > 16,384 (q' / mean(q')
+                              // can reach L_total; M_base is bounded by the weights, pf_lib.hip::check_f16_ranges)
 };
 
 // A block handles `iters` groups of four pairs one after the other: the 64 out_proj weights a thread holds are
@@ -1043,6 +1085,7 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     __shared__ float ctx[4][64];      // 4 pairs at a time
     __shared__ float mm[4][6][64];
     __shared__ float st[4][SROW];
+    __shared__ float rqs[4][4];
     const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
     // the out_proj column of this thread first: its latency hides behind the partial sums (a lone
     // alignment's forward is a chain of 26 such latencies)
@@ -1086,9 +1129,15 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
     if (ok) {
         const float* s = st[sub];
         const int hh = c >> 4;
-        const float sk = s[68 + hh], sq = s[64 + hh];
-        // (k / sum k)^T v, then q / mean(q): attention.py:183-192
-        ctx[sub][c] = (s[c] + bvc * sk) / sk * (a.L_total / sq);
+        const float sk = s[68 + hh];
+        // (k / sum k)^T v: attention.py:186-190 (a k'-weighted mean of v: bounded by the weights)
+        ctx[sub][c] = (s[c] + bvc * sk) / sk;
+        // q / mean(q), attention.py:183: the factor k_main multiplies q' with
+        if (c < 4) {
+            const float r = a.L_total / s[64 + c];
+            rqs[sub][c] = r;
+            a.rq[(size_t)pr * 4 + c] = r * a.b_scale;
+        }
     }
     __syncthreads();
     if (ok) {
@@ -1098,8 +1147,8 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
             float acc = 0.f;
 #pragma unroll
             for (int d = 0; d < 16; ++d) acc = fmaf(wo[hh][d], ctx[sub][16 * hh + d], acc);
-            if (m) m[hh * 64 + c] = acc;
-            mm[sub][hh][c] = acc;
+            if (m) m[hh * 64 + c] = acc * rqs[sub][hh];
+            mm[sub][hh][c] = acc * a.a_scale;
         }
         mm[sub][4][c] = biasc;
         mm[sub][5][c] = biascol;
@@ -1111,14 +1160,14 @@ __global__ void __launch_bounds__(256) k_rowfin(RowFinArgs a) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (i < 6) ? mm[sub][i][32 * To + t] : 0.f;
-        bf16x8 hi, lo;
+        frag_t hi, lo;
         split8(v, hi, lo);
-        bf16x8* mf = a.mfrag + (size_t)pr * MFRAG_PER_PAIR + To * 64 + t;
+        frag_t* mf = a.mfrag + (size_t)pr * MFRAG_PER_PAIR + To * 64 + t;
         mf[0] = hi;
         mf[32] = lo;
     }
-    // (the next group's st / ctx / mm writes are ordered behind this group's reads by the barriers above:
-    // st is rewritten before the first barrier, last read before the second; ctx and mm likewise one phase on)
+    // (the next group's st / ctx / rqs / mm writes are ordered behind this group's reads by the barriers above:
+    // st is rewritten before the first barrier, last read before the second; ctx, rqs and mm likewise one phase on)
     }
 }
 
@@ -1542,14 +1591,14 @@ __global__ void k_selftest(float* out) {
     out[64 + lane] = pair_other((float)lane, lane >> 5);
     out[128 + lane] = row16_sum((float)lane);
     out[192 + lane] = half32_sum((float)lane);
-    bf16x8 A1, A2, Bf;
+    frag_t A1, A2, Bf;
     const int m = lane & 31, kg = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = 8 * kg + i;
-        A1[i] = (__bf16)(float)(m + 32 * (k % 8));      // exact in bf16 (< 256)
-        A2[i] = (__bf16)(float)k;
-        Bf[i] = (__bf16)((k == (m & 15)) ? 1.f : 0.f);  // B[k][n = m] selects k == n % 16
+        A1[i] = (h16_t)(float)(m + 32 * (k % 8));      // exact in bf16 and fp16 (< 256)
+        A2[i] = (h16_t)(float)k;
+        Bf[i] = (h16_t)((k == (m & 15)) ? 1.f : 0.f);  // B[k][n = m] selects k == n % 16
     }
     f32x16 acc1, acc2;
 #pragma unroll
@@ -1562,5 +1611,7 @@ __global__ void k_selftest(float* out) {
         out[1280 + lane * 16 + r] = acc2[r];
     }
 }
+
+#endif  // PF_DEVICE_HELPERS_ONLY
 
 }  // namespace pfk

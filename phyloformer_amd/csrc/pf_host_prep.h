@@ -1,4 +1,4 @@
-// Host-side preparation of the device operands: bf16 hi/lo MFMA fragment images, LayerNorm folding, the block-0
+// Host-side preparation of the device operands: 16-bit hi/lo MFMA fragment images (fp16; bf16 with PF_F16 = 0), LayerNorm folding, the block-0
 // residue-pair table, and the shape-only launch plans (k_main's tiling, k_colstats' summation tree).
 // Plain C++ (no HIP): included by pf_lib.hip, and compiled on its own with g++ -fsanitize=address,undefined for the
 // fuzz tests (tests/test_native_sanitizers.py, tests/native/pf_host_prep_shim.cpp).
@@ -28,43 +28,65 @@ inline float bf2f(uint16_t b) {
     std::memcpy(&f, &u, 4);
     return f;
 }
+// ---- IEEE half helpers (host): round to nearest even, subnormals kept, overflow -> inf ----------
+inline uint16_t f2h(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint16_t sign = uint16_t((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return uint16_t(sign | 0x7c00u | (u > 0x7f800000u ? 0x200u : 0u));   // inf / nan
+    if (u >= 0x477ff000u) return uint16_t(sign | 0x7c00u);          // >= 65520 rounds to inf
+    if (u < 0x33000001u) return sign;                                // <= 2^-25 rounds to zero (2^-25 itself: ties to even)
+    const int e = int(u >> 23) - 127;                                // unbiased exponent
+    uint32_t m = (u & 0x7fffffu) | 0x800000u;                        // 24-bit significand
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                   // bits dropped (subnormal results drop more)
+    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+    uint32_t r = m >> shift;
+    if (rest > half || (rest == half && (r & 1u))) ++r;
+    // r carries the implicit bit for normal results: exponent field = e + 15 - 1, added with the carry
+    const uint32_t out = (e < -14) ? r : (uint32_t(e + 14) << 10) + r;
+    return uint16_t(sign | out);
+}
+inline float h2f(uint16_t hbits) {
+    const uint32_t sign = uint32_t(hbits & 0x8000u) << 16;
+    const int e = (hbits >> 10) & 0x1f;
+    const uint32_t m = hbits & 0x3ffu;
+    float mag;
+    if (e == 0) mag = std::ldexp((float)m, -24);
+    else if (e == 31) mag = m ? NAN : INFINITY;
+    else mag = std::ldexp((float)(m | 0x400u), e - 25);
+    uint32_t u;
+    std::memcpy(&u, &mag, 4);
+    u |= sign;
+    std::memcpy(&mag, &u, 4);
+    return mag;
+}
+// the format the device's split operands use (pf_layout.h: PF_F16)
+#if PF_F16
+inline uint16_t f2x(float f) { return f2h(f); }
+inline float x2f(uint16_t b) { return h2f(b); }
+#else
+inline uint16_t f2x(float f) { return f2bf(f); }
+inline float x2f(uint16_t b) { return bf2f(b); }
+#endif
 inline int kmap_h(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
 
 // Pack W[M][K] (row-major fp32) into MFMA A fragments, hi/lo split:
 //   out[((T * (K/16) + s) * 2 + hl) * 64 + lane][i] = W[32T + (lane & 31)][kmap(8s + i, lane >> 5)]
 // (rows >= M are zero).  K order matches the lane ownership of the B operand.
-inline void pack_frags(const float* W, int M, int K, int Mpad, uint16_t* out) {
+inline void pack_frags(const float* W, int M, int K, int Mpad, uint16_t* out, float scale = 1.f) {
     const int nT = Mpad / 32, nS = K / 16;
     for (int T = 0; T < nT; ++T)
         for (int s = 0; s < nS; ++s)
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 8; ++i) {
                     const int m = 32 * T + (lane & 31), k = kmap_h(8 * s + i, lane >> 5);
-                    const float w = (m < M) ? W[(size_t)m * K + k] : 0.f;
-                    const uint16_t hi = f2bf(w);
-                    const uint16_t lo = f2bf(w - bf2f(hi));
+                    const float w = (m < M) ? W[(size_t)m * K + k] * scale : 0.f;     // (scale: a power of two)
+                    const uint16_t hi = f2x(w);
+                    const uint16_t lo = f2x(w - x2f(hi));
                     const size_t base = ((size_t)(T * nS + s) * 2) * 64;
                     out[(base + lane) * 8 + i] = hi;
                     out[(base + 64 + lane) * 8 + i] = lo;
-                }
-}
-
-// Same fragment order with three bf16 terms (hi, mid, lo): out[((T * (K/16) + s) * 3 + term) * 64 + lane][i]
-inline void pack_frags3(const float* W, int M, int K, uint16_t* out) {
-    const int nT = M / 32, nS = K / 16;
-    for (int T = 0; T < nT; ++T)
-        for (int s = 0; s < nS; ++s)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 8; ++i) {
-                    const float w = W[(size_t)(32 * T + (lane & 31)) * K + kmap_h(8 * s + i, lane >> 5)];
-                    const uint16_t t0 = f2bf(w);
-                    const float r1 = w - bf2f(t0);
-                    const uint16_t t1 = f2bf(r1);
-                    const uint16_t t2 = f2bf(r1 - bf2f(t1));
-                    const size_t base = ((size_t)(T * nS + s) * 3) * 64;
-                    out[(base + lane) * 8 + i] = t0;
-                    out[(base + 64 + lane) * 8 + i] = t1;
-                    out[(base + 128 + lane) * 8 + i] = t2;
                 }
 }
 
@@ -77,7 +99,7 @@ inline void pack_qk_frags(const float* wq, const float* wk, uint16_t* qk) {
                 for (int i = 0; i < 8; ++i) {
                     const int k = kmap_h(8 * s + i, kg);
                     const float w = (m < 4) ? wq[(size_t)m * E + k] : wk[(size_t)(m - 4) * E + k];
-                    const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+                    const uint16_t hi = f2x(w), lo = f2x(w - x2f(hi));
                     qk[(((size_t)s * 2 + 0) * 16 + kg * 8 + m) * 8 + i] = hi;
                     qk[(((size_t)s * 2 + 1) * 16 + kg * 8 + m) * 8 + i] = lo;
                 }

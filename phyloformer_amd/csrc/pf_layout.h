@@ -3,6 +3,12 @@
 // AddressSanitizer / UBSan for the fuzz tests (tests/test_native_sanitizers.py).
 #pragma once
 
+// 16-bit format of the split MFMA operands: 1 = IEEE half (default), 0 = bfloat16 (rounds 1-5; A/B builds only).
+// pf_device.hip.h explains the choice; pf_host_prep.h packs the weights accordingly.
+#ifndef PF_F16
+#define PF_F16 1
+#endif
+
 namespace pfk {
 
 constexpr int E = 64;        // embed_dim
@@ -15,7 +21,7 @@ constexpr int MROW = 4 * 64; // folded row mix per pair: M[h][c], 4 heads (the b
                              // k_colstats keeps it in registers, the MFMA fragments carry it in K slot 4)
 constexpr float LN_EPS = 1e-5f;
 
-// LDS image of one block's MFMA A operands (bf16x8 fragments, 16 B per lane):
+// LDS image of one block's MFMA A operands (fragments of 8 16-bit values, 16 B per lane):
 //   W1' : [8 T][4 s][2 hi/lo][64 lanes]      64 KB   (FFN 64->256, LN affine folded)
 //   W2  : [2 To][16 s][2][64]                64 KB   (FFN 256->64)
 //   Woc : [2 To][4 s][2][64]                 16 KB   (column out_proj)
@@ -28,7 +34,7 @@ constexpr int FRAG_WO = FRAG_W2 + 2 * 16 * 2 * 64;           // [2 To][4 s][2][6
 constexpr int FRAG_WV = FRAG_WO + 2 * 4 * 2 * 64;            // next row attn Wv' hi only: [2 T][4 s][64]
 constexpr int FRAG_QK = FRAG_WV + 2 * 4 * 64;                // next row attn [Wq';Wk'] rows 0..7 only:
                                                              //   [4 s][2 hi/lo][2 kgrp][8 rows]
-constexpr int FRAG_END = FRAG_QK + 4 * 2 * 16;               // in bf16x8 (16-byte) units
+constexpr int FRAG_END = FRAG_QK + 4 * 2 * 16;               // in fragment (16-byte) units
 constexpr int WVLO_FRAGS = 2 * 4 * 64;                       // lo part of Wv', read from global
 constexpr int CONST_B1 = 0, CONST_B2 = 256, CONST_BQK = 320, CONST_HW = 328, CONST_HB = 392,
               CONST_BOC = 400;

@@ -1,7 +1,7 @@
 // libphyloformer_amd.so — host side of the C ABI declared in include/phyloformer_amd.h.
 //
 // Owns: the device, two streams, the prepared weights (fp32 folded copies and
-// split-bf16 MFMA fragment images), two grow-only workspaces, the optional RCCL
+// split-fp16 MFMA fragment images), two grow-only workspaces, the optional RCCL
 // communicator and the launch sequence of the forward pass
 // (reference: phyloformer/model.py:166-187).
 //
@@ -355,7 +355,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         std::vector<uint16_t> img((size_t)FRAG_END * 8);
         pack_frags(w1f.data(), FF, E, FF, img.data() + (size_t)FRAG_W1 * 8);
         pack_frags(w2s.data(), E, FF, E, img.data() + (size_t)FRAG_W2 * 8);
-        pack_frags(cols[k].wo, E, E, E, img.data() + (size_t)FRAG_WO * 8);
+        pack_frags(cols[k].wo, E, E, E, img.data() + (size_t)FRAG_WO * 8, COLAPPLY_A_SCALE);   // B side carries the inverse
         if (k + 1 < nb) std::copy(row_tail[k + 1].begin(), row_tail[k + 1].end(), img.begin() + (size_t)FRAG_WV * 8);
         if ((rc = upload(h, img, &d.wimg))) return rc;
         std::vector<float> cst(CONST_LEN, 0.f);
@@ -397,12 +397,12 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 TilePlan tile_plan(const pf_handle* h, int P, int Lloc) { return tile_plan_core(P, Lloc, h->tile_force); }
 
 struct Workspace {
-    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag, *spart, *outpart;
+    float *x, *qrow, *qcol, *srow, *mrow, *part, *ctx, *mfrag, *spart, *outpart, *rq;
     int G;             // pair groups of k_colstats
     int sub, S, fine;  // runs of `sub` pairs, S per group; fine: one block per run instead of per group
     int nparts() const { return fine ? G * S : G; }
 };
-constexpr int WS_BUFS = 10;
+constexpr int WS_BUFS = 11;
 
 void colstats_plan(const pf_handle* h, int B, int P, int Lloc, Workspace* w) {
     const ColPlan c = colstats_plan_core(B, P, Lloc, h->colstats_fine);
@@ -423,6 +423,7 @@ size_t workspace_bytes(const pf_handle* h, int B, int P, int Lloc, int nparts, s
     const size_t slots = (size_t)tile_plan(h, P, Lloc).slots_aln;
     off[8] = o; o = align_up(o + (size_t)B * slots * SROW * 4, 256);   // spart: row statistics per tile part
     off[9] = o; o = align_up(o + (size_t)B * slots * 4, 256);          // outpart: head sums per tile part
+    off[10] = o; o = align_up(o + (size_t)B * P * 4 * 4, 256);         // rq: L / S_q per pair and head
     return o;
 }
 
@@ -447,6 +448,7 @@ int ensure_workspace(pf_handle* h, int B, int P, int Lloc, Workspace* w, bool se
     w->ctx = (float*)(ws + off[6]);
     w->mfrag = (float*)(ws + off[7]);
     w->spart = (float*)(ws + off[8]); w->outpart = (float*)(ws + off[9]);
+    w->rq = (float*)(ws + off[10]);
     return PF_OK;
 }
 
@@ -528,7 +530,7 @@ struct ShardRun {
 MainArgs main_args(pf_handle* h, const ShardRun& r) {
     MainArgs m{};
     m.x = r.w.x; m.qrow = r.w.qrow; m.qcol = r.w.qcol;
-    m.mfrag = reinterpret_cast<const bf16x8*>(r.w.mfrag); m.ctx = r.w.ctx; m.spart = r.w.spart;
+    m.mfrag = reinterpret_cast<const frag_t*>(r.w.mfrag); m.rq = r.w.rq; m.ctx = r.w.ctx; m.spart = r.w.spart;
     m.outpart = r.w.outpart; m.table = h->table; m.idx = r.d_idx; m.pair_i = h->pair_i; m.pair_j = h->pair_j;
     m.B = r.B; m.N = r.N; m.P = r.P; m.Lloc = r.Lloc;
     m.flat = r.tp.flat; m.nt_aln = r.tp.nt_aln; m.slots_aln = r.tp.slots_aln;
@@ -550,8 +552,8 @@ int phase_first(pf_handle* h, const ShardRun& r) {
     int rc;
     if (h->embed_mfma) {
         MainArgs m = main_args(h, r);
-        m.wimg = reinterpret_cast<const bf16x8*>(h->first_img); m.consts = h->first_consts;
-        m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[0].wv_lo);
+        m.wimg = reinterpret_cast<const frag_t*>(h->first_img); m.consts = h->first_consts;
+        m.wv_lo = reinterpret_cast<const frag_t*>(h->blk[0].wv_lo);
         rc = launch_main<MODE_FIRST>(h, m, K_EMBED);
         if (rc) return rc;
     } else {
@@ -619,13 +621,19 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         if ((rc = save_tap(h, "srow" + std::to_string(k), rs.p, (size_t)B * P * SROW))) return rc;
     }
     {
-        RowFinArgs a{rs.p, w.mrow, reinterpret_cast<bf16x8*>(w.mfrag),
+        RowFinArgs a{rs.p, w.mrow, reinterpret_cast<frag_t*>(w.mfrag),
                      d.row_woT, d.row_bv, d.row_bo, d.col_bo,
                      B * P, rs.nparts, (float)r.L_total, rs.flat, P, Lloc, r.tp.slots_aln, 1};
         // enough blocks to fill the chip a few times over (8 x 256-thread blocks per CU), each amortising its
         // out_proj weights over `iters` groups of four pairs
         const int groups = (B * P + 3) / 4;
         a.iters = std::max(1, std::min(16, groups / (4 * 8 * std::max(1, h->prop.multiProcessorCount))));
+        a.rq = w.rq;
+        // q' / mean(q') can reach L_total: past 16,384 sites the B side of the row mix is scaled down by a power of
+        // two and the base matrix up (pf_device.hip.h, "fp16 operand ranges"); exact, and 1 for every usual shape
+        a.b_scale = 1.f;
+        for (long lim = 16384; lim < (long)r.L_total && a.b_scale > 1.f / 256.f; lim *= 2) a.b_scale *= 0.5f;
+        a.a_scale = 1.f / a.b_scale;
         ProfScope ps(h, K_ROWFIN);
         hipLaunchKernelGGL(k_rowfin, dim3((groups + a.iters - 1) / a.iters), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
@@ -652,10 +660,10 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         if ((rc = save_tap(h, "mrow" + std::to_string(k), w.mrow, (size_t)B * P * MROW))) return rc;
     }
     MainArgs m = main_args(h, r);
-    m.wimg = reinterpret_cast<const bf16x8*>(d.wimg);
+    m.wimg = reinterpret_cast<const frag_t*>(d.wimg);
     m.consts = d.consts;
     if (k + 1 < h->n_blocks) {
-        m.wv_lo = reinterpret_cast<const bf16x8*>(h->blk[k + 1].wv_lo);
+        m.wv_lo = reinterpret_cast<const frag_t*>(h->blk[k + 1].wv_lo);
         if (k == 0 && x0_on_the_fly(h)) rc = launch_main<MODE_MID0>(h, m, K_MAIN);
         else rc = launch_main<MODE_MID>(h, m, K_MAIN);
         if (rc) return rc;
@@ -1307,6 +1315,7 @@ int pf_forward_shards_emulated(pf_handle_t* h, const uint8_t* idx, int32_t B, in
         r.w.srow = (float*)(ws + off[3]); r.w.mrow = (float*)(ws + off[4]); r.w.part = (float*)(ws + off[5]);
         r.w.ctx = (float*)(ws + off[6]); r.w.mfrag = (float*)(ws + off[7]);
         r.w.spart = (float*)(ws + off[8]); r.w.outpart = (float*)(ws + off[9]);
+        r.w.rq = (float*)(ws + off[10]);
         std::vector<uint8_t> local((size_t)B * N * r.Lloc);
         for (int b = 0; b < B; ++b)
             for (int n = 0; n < N; ++n)
@@ -1364,7 +1373,7 @@ int pf_selftest(pf_handle_t* h, float* out) {
 // ---- softmax MultiHeadAttention (kernels in pf_mha.hip.h) -------------------
 struct pf_mha {
     pf_handle* h = nullptr;
-    float* wfrag = nullptr;   // MHA_WTOTAL bf16x8 fragments: Wq, Wk (3 terms), Wv, Wo (2 terms)
+    float* wfrag = nullptr;   // MHA_WTOTAL fragments: Wq, Wk, Wv, Wo as hi / lo
     float* bias = nullptr;    // [4][64]
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -1386,8 +1395,8 @@ int pf_mha_create(pf_handle_t* h, const pf_mha_weights_t* w, pf_mha_t** out) {
         if (!ws[i] || !bs[i]) return fail(h, PF_EINVAL, "pf_mha_create: NULL weight pointer");
         std::copy(bs[i], bs[i] + E, bias.begin() + i * E);
     }
-    pack_frags3(w->wq, E, E, img.data());
-    pack_frags3(w->wk, E, E, img.data() + (size_t)MHA_OFF_WK * 8);
+    pack_frags(w->wq, E, E, E, img.data());
+    pack_frags(w->wk, E, E, E, img.data() + (size_t)MHA_OFF_WK * 8);
     pack_frags(w->wv, E, E, E, img.data() + (size_t)MHA_OFF_WV * 8);
     pack_frags(w->wo, E, E, E, img.data() + (size_t)MHA_OFF_WO * 8);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1429,7 +1438,7 @@ int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, i
         return fail(h, PF_EINVAL, "pf_mha_forward: B*R*C too large for one launch");
     const int rows = (int)rows64;
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t qk_bytes = align_up((size_t)3 * rows * MHA_H * ntiles * 32 * 2 * 16, 256);
+    const size_t qk_bytes = align_up((size_t)2 * rows * MHA_H * ntiles * 32 * 2 * 16, 256);
     const size_t v_bytes = align_up((size_t)2 * rows * MHA_H * ntiles * 64 * 16, 256);
     const size_t att_bytes = align_up((size_t)rows * C * E * 4, 256);
     const size_t need = 2 * qk_bytes + v_bytes + att_bytes;
@@ -1440,11 +1449,11 @@ int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, i
     }
     MhaArgs a;
     a.x = d_x; a.y = d_y;
-    a.qp = (bf16x8*)m->ws;
-    a.kp = (bf16x8*)(m->ws + qk_bytes);
-    a.vp = (bf16x8*)(m->ws + 2 * qk_bytes);
+    a.qp = (frag_t*)m->ws;
+    a.kp = (frag_t*)(m->ws + qk_bytes);
+    a.vp = (frag_t*)(m->ws + 2 * qk_bytes);
     a.att = (float*)(m->ws + 2 * qk_bytes + v_bytes);
-    a.wfrag = (const bf16x8*)m->wfrag;
+    a.wfrag = (const frag_t*)m->wfrag;
     a.bias = m->bias;
     a.rows = rows; a.C = C; a.ntiles = ntiles;
     a.qscale = (float)(1.4426950408889634 / std::sqrt((double)MHA_D));
@@ -1453,19 +1462,19 @@ int pf_mha_forward_device(pf_mha_t* m, const float* d_x, int32_t B, int32_t R, i
     const int g1 = std::max(1, std::min((lin_tiles + 3) / 4, cus * 3));
     {
         ProfScope ps(h, K_MHA_QKV);
-        hipLaunchKernelGGL(k_mha_qkv, dim3(g1), dim3(256), 0, h->stream, a);
+        launch_mha_qkv(h->stream, (unsigned)g1, a);
     }
     HIPCHK(h, hipGetLastError());
     {
         ProfScope ps(h, K_MHA_ATTN);
-        hipLaunchKernelGGL(k_mha_attn, dim3(rows * MHA_H * ((ntiles + 3) / 4)), dim3(256), 0, h->stream, a);
+        launch_mha_attn(h->stream, (unsigned)(rows * MHA_H * ((ntiles + 3) / 4)), a);
     }
     HIPCHK(h, hipGetLastError());
     const int64_t out_tiles = ((int64_t)rows * C + 31) / 32;
     const int g3 = (int)std::max<int64_t>(1, std::min<int64_t>((out_tiles + 3) / 4, cus * 8));
     {
         ProfScope ps(h, K_MHA_OUT);
-        hipLaunchKernelGGL(k_mha_out, dim3(g3), dim3(256), 0, h->stream, a);
+        launch_mha_out(h->stream, (unsigned)g3, a);
     }
     HIPCHK(h, hipGetLastError());
     return PF_OK;

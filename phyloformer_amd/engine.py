@@ -23,6 +23,15 @@ UNIQUE_ID_BYTES = 256      # PF_UNIQUE_ID_BYTES: two ncclUniqueIds, one per comm
 PF_OK, PF_EINVAL, PF_EHIP, PF_ERCCL, PF_ENOMEM, PF_ESTATE = 0, -1, -2, -3, -4, -5
 
 
+def _refuse_single_sequence(B: int, N: int):
+    """One sequence = no pair: the reference's forward raises RuntimeError there (attention.py:193 cannot view the empty
+    tensor; pinned by tests/golden/cli_bad_entry.json), the C ABI answers PF_EINVAL for any N < 2 - the host mirror
+    raises what the reference raises."""
+    if N == 1 and B >= 1:
+        raise RuntimeError(f"cannot reshape tensor of 0 elements into shape [{B}, -1, 0, 64] because the unspecified "
+                           "dimension size -1 can be any value and is ambiguous")
+
+
 class EngineError(RuntimeError):
     """A HIP / RCCL / allocation failure reported by the native library."""
 
@@ -207,6 +216,7 @@ class Engine:
         if idx.ndim != 3:
             raise ValueError(f"idx must be [B, N, L] or [N, L], got shape {idx.shape}")
         B, N, L = idx.shape
+        _refuse_single_sequence(B, N)
         out = np.empty((B, N * (N - 1) // 2), dtype=np.float32)
         self._check(self._lib.pf_forward(self._h, idx.ctypes.data, B, N, L, out.ctypes.data))
         return out[0] if single else out
@@ -218,6 +228,7 @@ class Engine:
         if single:
             idx = idx[None]
         B, N, Ll = idx.shape
+        _refuse_single_sequence(B, N)
         if Ll != l_end - l_begin:
             raise ValueError(f"idx has {Ll} sites, expected {l_end - l_begin}")
         out = np.empty((B, N * (N - 1) // 2), dtype=np.float32)

@@ -61,14 +61,25 @@ def auto_batch(n_seqs: int, n_sites: int, max_batch: int = 4096, token_budget: i
     return int(min(max_batch, max(1, token_budget // tokens)))
 
 
+HEARTBEAT = "#pf-heartbeat"      # stderr line prefix of a site-sharded worker's sign of life (swallowed by the launcher)
 MAX_SEQS = 200     # SEQ2PAIR = seq2pair(200), /root/reference/phyloformer/model.py:39
 
 
-def too_many_seqs(n_seqs: int) -> Optional[ValueError]:
-    """The reference's forward refuses more than 200 sequences (adaptable_seq2pair, model.py:24-28) when the loop reaches
-    that file; the runner raises the same error at the same place in the order - after the files in front of it."""
+def single_sequence_error(batch: int = 1) -> RuntimeError:
+    """An alignment of ONE sequence parses (data.py:11-31) but has no pair: the reference's forward fails on the empty
+    tensor in attention.py:193 with this RuntimeError (tests/golden/cli_bad_entry.json, from the real CLI)."""
+    return RuntimeError(f"cannot reshape tensor of 0 elements into shape [{batch}, -1, 0, 64] because the unspecified "
+                        "dimension size -1 can be any value and is ambiguous")
+
+
+def too_many_seqs(n_seqs: int) -> Optional[Exception]:
+    """The reference's forward refuses more than 200 sequences (ValueError, adaptable_seq2pair, model.py:24-28) and fails
+    on a single one (RuntimeError, attention.py:193) when the loop reaches that file; the runner raises the same error at
+    the same place in the order - after the files in front of it."""
     if n_seqs > MAX_SEQS:
         return ValueError(f"n_seqs must be smaller or equal to {MAX_SEQS} (or pre-compute a larger global_seq2pair)")
+    if n_seqs == 1:
+        return single_sequence_error()
     return None
 
 
@@ -298,7 +309,7 @@ class DirectoryRunner:
             t0 = time.perf_counter()
             fb = inflight.popleft().result()
             self.stats["load_wait_s"] += time.perf_counter() - t0
-            ok = (fb.status == 0) & (fb.l > 0) & (fb.n <= MAX_SEQS)
+            ok = (fb.status == 0) & (fb.l > 0) & (fb.n <= MAX_SEQS) & (fb.n != 1)
             stop = len(fb) if ok.all() else int(np.argmin(ok))
             if stop < len(fb):
                 bad = fb.error(stop) or too_many_seqs(int(fb.n[stop]))
@@ -342,10 +353,21 @@ class SiteShardedRunner(DirectoryRunner):
     ranks compare (shape, batch, checksum of the file names) through the rendezvous: a directory that differs
     between ranks is an error on all of them, not a hang."""
 
-    def __init__(self, engine, group, rank: int, world: int, out_dir: str, **kw):
+    def __init__(self, engine, group, rank: int, world: int, out_dir: str, heartbeat_s: Optional[float] = None, **kw):
         super().__init__([engine], out_dir, **kw)
         self.group, self.rank, self.world = group, rank, world
         self.stats["site_sharded_over"] = world
+        # A worker of `--devices ... --shard sites` prints nothing until its report (no progress bar): the launcher's
+        # stall watchdog (run_multi_device) would take a long healthy run for a hang.  Every `heartbeat_s` seconds of
+        # progress the rank says so on stderr (ADVICE r05); the launcher swallows these lines.
+        self.heartbeat_s = heartbeat_s
+        self._last_beat = time.monotonic()
+
+    def _beat(self):
+        if self.heartbeat_s is not None and time.monotonic() - self._last_beat >= self.heartbeat_s:
+            self._last_beat = time.monotonic()
+            print(f"{HEARTBEAT} rank {self.rank}: {self.stats['alignments']} alignments in {self.stats['launches']} launches",
+                  file=sys.stderr, flush=True)
 
     def _launch_sharded(self, shape, group_items, writers, pending):
         import zlib
@@ -373,6 +395,7 @@ class SiteShardedRunner(DirectoryRunner):
                 pending.popleft().result()
         if self.progress is not None:
             self.progress(len(group_items))
+        self._beat()
 
     def run(self, paths: Sequence[str]) -> dict:
         for p in paths:
@@ -402,6 +425,7 @@ class SiteShardedRunner(DirectoryRunner):
                 t0 = time.perf_counter()
                 idx, ids = fut.result()
                 self.stats["load_wait_s"] += time.perf_counter() - t0
+                self._beat()                 # (parsing a long run of files that fill no bucket is progress too)
                 shape = (int(idx.shape[0]), int(idx.shape[1]))
                 bucket = buckets.setdefault(shape, [])
                 bucket.append((path, idx, ids))
@@ -519,9 +543,13 @@ def run_multi_device(script: str, argv: List[str], devices: Sequence[int], shard
             time.sleep(0.05)
     for t in readers:
         t.join(timeout=5)
-    rc, reports = 0, []
+    # Exit code: the first rank that FAILED ON ITS OWN decides (or 124 for a stall) - not the -15 of a peer this
+    # launcher terminated, which may have a lower rank number; a child ended by a signal counts as 128 + signal.
+    def code_of(c):
+        return 1 if c is None else (128 - c if c < 0 else c)
+    rc, reports = (code_of(failed[1]) or 1) if failed is not None else 0, []
     for k, p in enumerate(procs):
-        rc = rc or (p.returncode if p.returncode is not None else 1)
+        rc = rc or code_of(p.returncode)
         rep = None
         for line in "".join(lines[k]).splitlines():
             if line.startswith("{") and '"alignments"' in line:
@@ -530,10 +558,8 @@ def run_multi_device(script: str, argv: List[str], devices: Sequence[int], shard
                     continue
                 except ValueError:
                     pass
-            if line.strip():
+            if line.strip() and not line.startswith(HEARTBEAT):
                 print(line, file=sys.stderr)
         if rep is not None:
             reports.append(rep)
-    if failed is not None and rc == 0:
-        rc = failed[1] or 1
     return rc, reports

@@ -40,7 +40,7 @@ class OracleEngine:
             # the way a real ncclCommInitRank reports a bootstrap error on every rank)
             self.comm = TcpGroup(rank, world, key="oracle_comm_" + bytes(uid)[:16].hex(),
                                  timeout=4 if os.environ.get("PF_FAKE_FAIL_COMM_ON") else
-                                 600 if os.environ.get("PF_FAKE_DIE_RANK") else 60)
+                                 600 if (os.environ.get("PF_FAKE_DIE_RANK") or os.environ.get("PF_FAKE_HANG_RANK")) else 60)
 
     def comm_destroy(self):
         self.close()
@@ -69,6 +69,12 @@ class OracleEngine:
     def forward_sharded(self, idx_local, lo, hi, L):
         if os.environ.get("PF_FAKE_DIE_RANK") == str(self.rank) and self.ncoll > 0:
             os._exit(7)                              # a rank lost mid-run (OOM kill, HIP error): its peers wait in a collective
+        if os.environ.get("PF_FAKE_SLOW_S"):          # a long healthy launch (the stall watchdog must not take it for a hang)
+            import time
+            time.sleep(float(os.environ["PF_FAKE_SLOW_S"]))
+        if os.environ.get("PF_FAKE_HANG_RANK") == str(self.rank) and self.ncoll > 0:
+            import time
+            time.sleep(3600)                         # a rank that stops making progress without dying
         idx_local = np.asarray(idx_local, np.uint8)
         assert idx_local.shape[-1] == hi - lo
         return np.stack([O.forward_rank(self.w, a, L, self._allreduce) for a in idx_local])

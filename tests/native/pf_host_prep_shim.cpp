@@ -9,8 +9,11 @@ extern "C" {
 
 // out: (Mpad / 32) * (K / 16) * 2 * 64 * 8 uint16
 void t_pack_frags(const float* W, int M, int K, int Mpad, uint16_t* out) { pack_frags(W, M, K, Mpad, out); }
-// out: (M / 32) * (K / 16) * 3 * 64 * 8 uint16
-void t_pack_frags3(const float* W, int M, int K, uint16_t* out) { pack_frags3(W, M, K, out); }
+// the host's float -> IEEE half -> float conversions (what packs the weights; the device's v_cvt_pk_f16_f32 agrees
+// bit for bit, tools/f16_probe.hip)
+void t_f2h(const float* in, uint16_t* out, int n) { for (int i = 0; i < n; ++i) out[i] = f2h(in[i]); }
+void t_h2f(const uint16_t* in, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = h2f(in[i]); }
+int t_operand_format() { return PF_F16; }
 // tail: (FRAG_END - FRAG_WV) * 8 uint16, wv_lo: WVLO_FRAGS * 8 uint16
 void t_pack_row_stats(const float* wv, const float* wq, const float* wk, uint16_t* tail, uint16_t* wv_lo) {
     pack_row_stats(wv, wq, wk, tail, wv_lo);

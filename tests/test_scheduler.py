@@ -92,12 +92,13 @@ def test_directory_runner_trees_and_errors(tmp_path):
 
 
 @pytest.mark.parametrize("native_io", [True, False])
-@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue", "too_many_seqs"])
+@pytest.mark.parametrize("scenario", ["bad_extension", "bad_residue", "too_many_seqs", "single_sequence"])
 def test_bad_entry_side_effects_are_the_references(tmp_path, golden, scenario, native_io):
     """VERDICT r04 / next 7.  The reference handles one directory entry after the other (infer_alns.py:97-117): when it
     meets an entry without a FASTA extension (ValueError, :100-103), a file that does not parse (KeyError from
-    load_alignment, data.py:26) or an alignment of more than 200 sequences (ValueError from adaptable_seq2pair inside the
-    forward, model.py:24-28), every entry listed BEFORE it has its .phy and nothing after it does.  The fixture
+    load_alignment, data.py:26), an alignment of more than 200 sequences (ValueError from adaptable_seq2pair inside the
+    forward, model.py:24-28) or of a single one (RuntimeError from attention.py:193: no pair to view - round 6), every
+    entry listed BEFORE it has its .phy and nothing after it does.  The fixture
     (oracle/gen_golden_cli_errors.py) holds what the real CLI left behind; this build's runner, batching and
     prefetching notwithstanding, must leave the same set for the same processing order, and raise the same."""
     g = json.load(open(os.path.join(REPO, "tests", "golden", "cli_bad_entry.json")))[scenario]
@@ -110,12 +111,13 @@ def test_bad_entry_side_effects_are_the_references(tmp_path, golden, scenario, n
     for name in order:
         if name == offender:
             (d / name).write_bytes({"bad_extension": b"not an alignment\n", "bad_residue": b">s0\nARNDB\n>s1\nARNDC\n",
-                                    "too_many_seqs": "".join(f">t{k}\nAR{'N' if k % 2 else 'D'}\n" for k in range(201)).encode()}[scenario])
+                                    "too_many_seqs": "".join(f">t{k}\nAR{'N' if k % 2 else 'D'}\n" for k in range(201)).encode(),
+                                    "single_sequence": b">s0\nARNDCQEGHILK\n"}[scenario])
         else:
             _write_fasta(d / name, rng.integers(0, 20, (5, 12)).astype(np.uint8))
     out = tmp_path / "out"
     out.mkdir()
-    exc = {"ValueError": ValueError, "KeyError": KeyError}[g["exception"]]
+    exc = {"ValueError": ValueError, "KeyError": KeyError, "RuntimeError": RuntimeError}[g["exception"]]
     with pytest.raises(exc) as info:
         scheduler.DirectoryRunner([FakeEngine(), FakeEngine()], str(out), io_threads=3, native_io=native_io,
                                   batch=2).run([str(d / n) for n in order])
@@ -270,9 +272,36 @@ def test_cli_site_sharded_dead_rank_ends_the_run_instead_of_hanging(small_dir, t
     t0 = time.time()
     r = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "dead"), "--devices", "0,1", "--shard", "sites", "--batch", "1"], env,
              timeout=200)
-    assert r.returncode != 0
+    assert r.returncode == 7, r.returncode        # the code of the rank that failed on its own, not a terminated peer's -15
     assert "rank 1 exited with code 7; terminating the other site-sharded ranks" in r.stderr
     assert time.time() - t0 < 120
+
+
+def test_cli_site_sharded_slow_healthy_run_survives_the_stall_watchdog(small_dir, tmp_path):
+    """site-sharded workers print nothing until their report, so a healthy run longer than
+    PF_CLI_STALL_TIMEOUT used to be terminated with partial outputs.  Workers now send a heartbeat line while they make
+    progress; the launcher counts it as an event and keeps it out of its own stderr.  Six launches of 1 s each against a
+    3 s stall limit."""
+    env = {"PF_CLI_ENGINE_FACTORY": "helpers.oracle_engine:make", "PF_FAKE_SLOW_S": "1.0", "PF_CLI_STALL_TIMEOUT": "3",
+           "PF_CLI_HEARTBEAT": "0.5", "TMPDIR": str(tmp_path)}
+    ckpt = os.path.join(REPO, "models", "pf_base.ckpt")
+    r = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "slow"), "--devices", "0,1", "--shard", "sites", "--batch", "1"], env,
+             timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(os.listdir(tmp_path / "slow")) == 6
+    assert scheduler.HEARTBEAT not in r.stderr and "terminating" not in r.stderr
+
+
+def test_cli_site_sharded_stalled_rank_is_reported_as_a_stall(small_dir, tmp_path):
+    """A rank that stops (no line, no exit) does end the run after PF_CLI_STALL_TIMEOUT, and the exit code says why:
+    124, not the -15 / 241 of the peers the launcher itself terminated."""
+    env = {"PF_CLI_ENGINE_FACTORY": "helpers.oracle_engine:make", "PF_FAKE_HANG_RANK": "1", "PF_CLI_STALL_TIMEOUT": "4",
+           "PF_CLI_HEARTBEAT": "0.5", "TMPDIR": str(tmp_path)}
+    ckpt = os.path.join(REPO, "models", "pf_base.ckpt")
+    r = _cli([ckpt, str(small_dir), "-o", str(tmp_path / "hang"), "--devices", "0,1", "--shard", "sites", "--batch", "1"], env,
+             timeout=300)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert "no rank made progress for 4 s; terminating the other site-sharded ranks" in r.stderr
 
 
 def test_stale_partial_buckets_are_launched_not_hoarded(tmp_path):

@@ -14,20 +14,19 @@ from phyloformer_amd import build as B
 def main():
     args = sys.argv[1:]
     out = os.path.join(REPO, "phyloformer_amd", args.pop(0))
-    src = REPO
     if args and args[0] == "--src":
         src = os.path.abspath(args[1]); args = args[2:]
-    sources = [os.path.join(src, "phyloformer_amd", "csrc", f) for f in ("pf_lib.hip", "pf_hostio.cpp")]
-    sched = [] if "--default-sched" in args else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
-    args = [a for a in args if a != "--default-sched"]
+        B.CSRC = os.path.join(src, "phyloformer_amd", "csrc")          # another checkout's sources, this checkout's recipe
+        B.INCLUDE = os.path.join(src, "include")
+        B.UNITS = {u: f for u, f in B.UNITS.items() if os.path.exists(os.path.join(B.CSRC, u))}
+        B.HEADERS = [h for h in B.HEADERS if os.path.exists(os.path.join(B.CSRC, h))]
+    if "--default-sched" in args:
+        args = [a for a in args if a != "--default-sched"]
+        B.UNITS["pf_lib.hip"] = [f for f in B.UNITS["pf_lib.hip"] if f not in B.SCHED]
     if "--sched" in args:                       # another scheduling strategy: --sched max-ilp
         k = args.index("--sched")
-        sched = ["-mllvm", f"-amdgpu-sched-strategy={args[k + 1]}"]
+        B.UNITS["pf_lib.hip"] = [f for f in B.UNITS["pf_lib.hip"] if f not in B.SCHED] + ["-mllvm", f"-amdgpu-sched-strategy={args[k + 1]}"]
+        B.SCHED = B.UNITS["pf_lib.hip"][-2:]
         del args[k:k + 2]
-    cmd = [B.hipcc_path(), f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize",
-           "-Wno-unused-value", *sched, *args, *sources, "-o", out, "-ldl"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode:
-        sys.stderr.write(res.stderr[-3000:]); sys.exit(1)
-    print(out)
+    print(B.build(force=True, out=out, extra=args))
 main()

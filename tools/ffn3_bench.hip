@@ -14,12 +14,13 @@
 #include <cstdlib>
 #include <vector>
 #include "../phyloformer_amd/csrc/pf_device.hip.h"
+#include "../phyloformer_amd/csrc/pf_host_prep.h"
 #include PF_HID_INC
 
 using namespace pfk;
 typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ u32x16 pack4(const bf16x8 (&f)[4]) {
+__device__ __forceinline__ u32x16 pack4(const frag_t (&f)[4]) {
     u32x16 r;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -42,7 +43,7 @@ static double mean_cycles() {
 enum { M_PLAIN = 0, M_HID2 = 1, M_HID1 = 2 };
 
 template <int MODE, int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid(const bf16x8* wimg, const float* consts, float* out,
+__global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid(const frag_t* wimg, const float* consts, float* out,
                                                                float* dump, int iters, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_frag_t lw = (lds_frag_t)smem;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid(const bf16x8* wi
 
     const unsigned long long tc0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
-        bf16x8 xh[NT][4], xl[NT][4];
+        frag_t xh[NT][4], xl[NT][4];
         f32x16 oa[NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -94,16 +95,16 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid(const bf16x8* wi
                     load_acc_bias(ha, bp);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const bf16x8 fh = f1[s * 128], fl = f1[s * 128 + 64];
+                        const frag_t fh = f1[s * 128], fl = f1[s * 128 + 64];
                         mfma3(ha, fh, fl, xh[t][s], xl[t][s]);
                     }
-                    bf16x8 g_hi[2], g_lo[2];
+                    frag_t g_hi[2], g_lo[2];
                     gelu_split8(ha, 0, g_hi[0], g_lo[0]);
                     gelu_split8(ha, 8, g_hi[1], g_lo[1]);
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
                         const int u = st >> 1, To = st & 1;
-                        const bf16x8 fh = f2[(To * 32 + u * 2) * 64], fl = f2[(To * 32 + u * 2) * 64 + 64];
+                        const frag_t fh = f2[(To * 32 + u * 2) * 64], fl = f2[(To * 32 + u * 2) * 64 + 64];
                         mfma3(oa[t][To], fh, fl, g_hi[u], g_lo[u]);
                     }
                 }
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid(const bf16x8* wi
 // so that the compiler-generated code around the asm needs only a handful of registers and the kernel
 // fits 2 waves per SIMD (176 pinned VGPRs + 64 pinned AGPRs).
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid1_lean(const bf16x8* wimg, const float* consts,
+__global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid1_lean(const frag_t* wimg, const float* consts,
                                                                      const u32x16* opnd, float* out, int iters,
                                                                      unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_hid1_lean(const bf16
 }
 
 template <int THREADS>
-void run_lean(const char* name, const bf16x8* wimg, const float* consts, const u32x16* opnd, float* out, int iters) {
+void run_lean(const char* name, const frag_t* wimg, const float* consts, const u32x16* opnd, float* out, int iters) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hid1_lean<THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         MAIN_LDS_BYTES);
     hipEvent_t a, b;
@@ -228,7 +229,7 @@ static std::vector<float> g_ref;
 
 
 template <int MODE, int THREADS>
-void run(const char* name, const bf16x8* wimg, const float* consts, float* out, float* dump, int iters) {
+void run(const char* name, const frag_t* wimg, const float* consts, float* out, float* dump, int iters) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hid<MODE, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         MAIN_LDS_BYTES);
     hipEvent_t a, b;
@@ -324,13 +325,17 @@ int main(int argc, char** argv) {
     const int iters = energy ? 2048 : 64;
     std::vector<uint16_t> img((size_t)FRAG_END * 8);
     for (size_t i = 0; i < img.size(); ++i) {
-        // W ~ +-[0.03, 0.12], deterministic
-        const uint32_t r = (uint32_t)(i * 2654435761u);
-        img[i] = zero ? 0 : (uint16_t)(0x3d00 + ((r >> 20) % 256) + ((r >> 9) & 1 ? 0x8000 : 0));
+        // W ~ +-[0.03, 0.12], deterministic; hi fragments hold the value rounded to the operand format, lo fragments
+        // (every second group of 64 in the W1 / W2 / Wo regions) its rounding residual - what the product image holds
+        const uint32_t r = (uint32_t)((i / 8 % 64 + (i / 1024) * 64) * 8 + i % 8) * 2654435761u;
+        const float w = (0.03f + 0.09f * (float)((r >> 20) % 256) / 256.f + 1e-5f * (float)((r >> 3) % 97)) * ((r >> 9) & 1 ? -1.f : 1.f);
+        const uint16_t hi = pfhost::f2x(w);
+        const bool lo_frag = (i / 8 / 64) % 2 == 1;
+        img[i] = zero ? 0 : (lo_frag ? pfhost::f2x(w - pfhost::x2f(hi)) : hi);
     }
     std::vector<float> cst(CONST_LEN);
     for (int i = 0; i < CONST_LEN; ++i) cst[i] = 0.05f * (float)((i * 37) % 21 - 10);
-    bf16x8* d_img; float *d_c, *d_out, *d_dump;
+    frag_t* d_img; float *d_c, *d_out, *d_dump;
     hipMalloc((void**)&d_img, img.size() * 2);
     hipMalloc((void**)&d_c, cst.size() * 4);
     hipMalloc((void**)&d_out, 256 * 512 * 4);
@@ -351,6 +356,7 @@ int main(int argc, char** argv) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             printf("energy idle                   %7.1f W\n", (smi.joules() - j0) / dt);
         }
+        if (!PF_F16)      // (the generated streams are written with the bf16 mnemonics)
         energy_run(smi, "asm two-tile 1w/SIMD", seconds, 256.0 * 4 * iters * 2, 1, [&] {
             hipLaunchKernelGGL((k_hid<M_HID2, 256>), dim3(256), dim3(256), MAIN_LDS_BYTES, 0, d_img, d_c, d_out, (float*)nullptr, iters, g_cyc);
         });

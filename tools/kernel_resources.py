@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phyloformer_amd import build as B
 
 def main():
-    out = os.path.join(tempfile.gettempdir(), "pf_res.so")
-    cmd = [B.hipcc_path(), f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize",
-           "-Wno-unused-value", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *sys.argv[1:], *B.SOURCES, "-o", out, "-ldl",
+    out = os.path.join(tempfile.gettempdir(), "pf_res.o")
+    unit = "pf_lib.hip"                          # the default-path kernels (k_main, k_colstats, ...)
+    cmd = [B.hipcc_path(), *B.COMMON, *B.UNITS[unit], *sys.argv[1:], "-c", os.path.join(B.CSRC, unit), "-o", out,
            "-Rpass-analysis=kernel-resource-usage"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode:
