@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 4
+#define PF_ABI_VERSION 5
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -286,7 +286,16 @@ int64_t pf_format_phylip(const float* preds, int32_t n, const char* const* ids, 
 int64_t pf_format_phylip_n(const float* preds, int32_t n, const char* const* ids, const int64_t* id_lens, char* out,
                            int64_t cap);
 
-/* ---- many files per call, on native threads (ABI 4) -----------------------------------------------
+/* pf_nj_newick_n replaces skbio.tree.nj + the tree's text for the CLI's --trees (infer_alns.py:62-64,120-123):
+ * neighbour joining (Saitou & Nei) on the symmetrised matrix of preds, float64 arithmetic, negative branch lengths
+ * clamped to zero when clamp_negative != 0 (scikit-bio's default), the last three clusters joined at a trifurcation;
+ * Newick text "(...);\n" with the ids as labels and Python-repr branch lengths - byte-identical to
+ * phyloformer_amd/nj.py, which is pinned against FastME -m N trees of the reference's distances.  Sizing protocol as
+ * pf_format_phylip (out = NULL, cap = 0 first). */
+int64_t pf_nj_newick_n(const float* preds, int32_t n, const char* const* ids, const int64_t* id_lens, int32_t clamp_negative,
+                       char* out, int64_t cap);
+
+/* ---- many files per call, on native threads (ABI 4; tree_paths: ABI 5) ---------------------------
  *
  * The CLI loop (infer_alns.py:97-117) opens, parses, formats and writes one small file per alignment.
  * pf_fasta_batch_load reads and parses `count` files on up to `threads` native threads (pf_parse_fasta's
@@ -294,7 +303,8 @@ int64_t pf_format_phylip_n(const float* preds, int32_t n, const char* const* ids
  * library-owned batch object; pf_fasta_batch_infos fills per-file arrays of length count;
  * pf_fasta_batch_gather copies the residue indices of `count` (batch, file) entries, all of shape n x l,
  * into dst [count][n][l] - the input of pf_forward; pf_phylip_write_batch formats preds [count][n(n-1)/2]
- * as pf_format_phylip does, with the sequence ids the batch objects hold, and writes out_paths[k] on up to
+ * as pf_format_phylip does, with the sequence ids the batch objects hold, and writes out_paths[k] - and, when
+ * tree_paths is not NULL, the pf_nj_newick_n text of the same distances to tree_paths[k] - on up to
  * `threads` threads: status[k] = 0 or -errno.  A batch object is immutable after load: any number of threads
  * may read it; free it once, after the last use. */
 typedef struct pf_fasta_batch pf_fasta_batch_t;
@@ -306,7 +316,8 @@ int pf_fasta_batch_id(const pf_fasta_batch_t* b, int32_t file, int32_t seq, cons
 int pf_fasta_batch_gather(const pf_fasta_batch_t* const* batches, const int32_t* file_idx, int32_t count, int32_t n,
                           int32_t l, uint8_t* dst);
 int pf_phylip_write_batch(const pf_fasta_batch_t* const* batches, const int32_t* file_idx, int32_t count, int32_t n,
-                          const float* preds, const char* const* out_paths, int32_t threads, int32_t* status);
+                          const float* preds, const char* const* out_paths, const char* const* tree_paths, int32_t threads,
+                          int32_t* status);
 
 #ifdef __cplusplus
 }

@@ -144,7 +144,7 @@ def build(force: bool = False, verbose: bool = False, out: str = LIB, extra: Opt
             sys.stderr.write("phyloformer_amd.build: WARNING - pf_lib.hip was compiled with hipcc's DEFAULT scheduling "
                              "strategy (sched_fallback: true in pf_build_info)\n")
         info = {
-            "abi": 4, "arch": ARCH, "hipcc": _hipcc_version(hipcc),
+            "abi": 5, "arch": ARCH, "hipcc": _hipcc_version(hipcc),
             "sched_strategy": "default" if fallback else "iterative-ilp", "sched_fallback": fallback,
             "flags": {u: " ".join(COMMON + f) for u, f in used.items()},
             "source_hash": source_hash(), "kernel_hash": kernel_hash(used["pf_lib.hip"]),

@@ -49,12 +49,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16_t;
 #define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define PF_DOT2C "v_dot2c_f32_f16"
+#define PF_CVT_PK "v_cvt_pk_f16_f32"
 #define PF_NEG1_LO 0x0000bc00u      // (-1, 0) and (0, -1) as packed pairs of the format
 #define PF_NEG1_HI 0xbc000000u
 #else
 typedef __bf16 h16_t;
 #define PF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define PF_DOT2C "v_dot2c_f32_bf16"
+#define PF_CVT_PK "v_cvt_pk_bf16_f32"
 #define PF_NEG1_LO 0x0000bf80u
 #define PF_NEG1_HI 0xbf800000u
 #endif
@@ -222,6 +224,7 @@ __device__ __forceinline__ float gelu_as(float x) {
 __device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // FFN hidden activation for two accumulator values at once, fused with the 16-bit hi/lo split.
@@ -257,12 +260,12 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
     const h16x2 h2 = {(h16_t)g0, (h16_t)g1};
     const unsigned hb = __builtin_bit_cast(unsigned, h2);
     float r0 = g0, r1 = g1;
-    // HAZARD (measured on gfx950, not interlocked): a VALU that reads the result of v_dot2c_f32_*
-    // needs >= 2 wait states after it (s_nop 0 gives wrong data, s_nop 1 is clean on every golden);
-    // hipcc pads nothing inside an asm statement, so the pad lives in the string, with one spare state.
+    // HAZARD (measured on gfx950, not interlocked): a VALU that reads the result of v_dot2c_f32_f16 needs >= 3 wait
+    // states after it (tools/f16_probe.hip: stale data after two; the bf16 form needs two); hipcc pads nothing
+    // inside an asm statement, so the pad lives in the string, with one spare state.
 #ifndef PF_DOT2C_PRE
 #define PF_DOT2C_PRE ""
-#define PF_DOT2C_POST "\n\ts_nop 2"
+#define PF_DOT2C_POST "\n\ts_nop 3"
 #endif
 #ifdef PF_SPLIT_NODOT
     // same residual through plain VALU (unpack / subtract): two more instructions per pair, but
@@ -304,21 +307,22 @@ __device__ __forceinline__ void split8(const float* v, frag_t& hi, frag_t& lo) {
         h[k] = __builtin_bit_cast(unsigned, h2);
     }
     float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7];
-    // not volatile: a pure function of its operands, so the scheduler may interleave the splits of
-    // independent splits instead of keeping every asm statement in program order
+    unsigned l0, l1, l2, l3;
+    // not volatile: a pure function of its operands, so the scheduler may interleave independent splits instead of
+    // keeping every asm statement in program order.  The conversions of the residuals sit INSIDE the block, in issue
+    // order: v_dot2c_f32_f16 needs >= 3 wait states before a VALU reads its result (tools/f16_probe.hip: two - enough
+    // for the bf16 form - return stale data), and outside the block hipcc is free to read the last residual first.
+    // Here the closest reader (of r7) is 2 + 3 = 5 wait states behind its dot2c.
     asm(
-        PF_DOT2C " %0, %8, %10\n\t" PF_DOT2C " %1, %9, %10\n\t"
-        PF_DOT2C " %2, %8, %11\n\t" PF_DOT2C " %3, %9, %11\n\t"
-        PF_DOT2C " %4, %8, %12\n\t" PF_DOT2C " %5, %9, %12\n\t"
-        PF_DOT2C " %6, %8, %13\n\t" PF_DOT2C " %7, %9, %13\n\ts_nop 1"
-        : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+        PF_DOT2C " %4, %12, %14\n\t" PF_DOT2C " %5, %13, %14\n\t"
+        PF_DOT2C " %6, %12, %15\n\t" PF_DOT2C " %7, %13, %15\n\t"
+        PF_DOT2C " %8, %12, %16\n\t" PF_DOT2C " %9, %13, %16\n\t"
+        PF_DOT2C " %10, %12, %17\n\t" PF_DOT2C " %11, %13, %17\n\ts_nop 1\n\t"
+        PF_CVT_PK " %0, %4, %5\n\t" PF_CVT_PK " %1, %6, %7\n\t" PF_CVT_PK " %2, %8, %9\n\t" PF_CVT_PK " %3, %10, %11"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3),
+          "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
         : "s"(PF_NEG1_LO), "s"(PF_NEG1_HI), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
-    const h16x2 l0 = {(h16_t)r0, (h16_t)r1}, l1 = {(h16_t)r2, (h16_t)r3}, l2 = {(h16_t)r4, (h16_t)r5},
-                 l3 = {(h16_t)r6, (h16_t)r7};
-    l[0] = __builtin_bit_cast(unsigned, l0);
-    l[1] = __builtin_bit_cast(unsigned, l1);
-    l[2] = __builtin_bit_cast(unsigned, l2);
-    l[3] = __builtin_bit_cast(unsigned, l3);
+    l[0] = l0; l[1] = l1; l[2] = l2; l[3] = l3;
     hi = __builtin_bit_cast(frag_t, h);
     lo = __builtin_bit_cast(frag_t, l);
 #endif
@@ -1243,18 +1247,35 @@ constexpr int CPART = 4 * 64 + 8;
 // 16-byte loads per lane).  Applies the row attention on the fly (it is not materialised in HBM), then
 // LayerNorm -> q', k' -> Z~ += k' x~.  Eight lanes per token: three steps per cross-lane reduction and,
 // after the transposing butterfly, exactly one projection per lane - 24 VALU instructions per token.
-template <bool EMBED>
+// RING > 0 (the x-reading variant only): the token rows and q' of the next RING pairs travel global -> LDS without
+// passing through registers (global_load_lds into a ring of RING slots per wave).  The register prefetch it replaces
+// reaches one iteration (two pairs) ahead - all that 244 VGPRs leave room for - and every iteration then started by
+// waiting for the loads issued one iteration earlier: with ~0.6 us of work per iteration against > 1 us of loaded HBM
+// latency the kernel was latency-bound (4.4 TB/s; cutting its VALU work by 37 % with packed math bought 7 %).  The ring
+// holds RING pairs in flight per wave whatever the register budget; same operations on the same values: same bits.
+constexpr int CS_SLOT = 2 * 256 + 64;       // floats per ring slot: 8 sites x 64 channels as two 16-byte halves per lane, q' [8][4] (+ 32 spare)
+#ifndef PF_CS_RING
+#define PF_CS_RING 4
+#endif
+template <bool EMBED, int RING>
 #ifndef PF_CS_WAVES
 #define PF_CS_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
-    // two staging buffers of 16 pair matrices (4 x 64 floats each)
-    __shared__ __attribute__((aligned(16))) float mst[2 * 16 * MROW];
-    __shared__ __attribute__((aligned(16))) float emb[EMBED ? 22 * 64 : 4];
+    static_assert(!(EMBED && RING), "block 0 reads residue bytes, not x");
+    static_assert(RING % 2 == 0, "pairs are consumed two at a time");
+    // ONE LDS object (hipcc, ROCm 7.2: with a second __shared__ object it orders every ds_read behind every outstanding
+    // global_load_lds - s_waitcnt vmcnt(0) - and the ring below would drain once per iteration; cdna_hip_programming.md):
+    //   two staging buffers of 16 pair matrices (4 x 64 floats each) | the ring | block 0: embedding table, pair indices
+    constexpr int LDS_MST = 2 * 16 * MROW, LDS_RING = RING ? 4 * RING * CS_SLOT : 0, LDS_EMB = EMBED ? 22 * 64 : 0;
     // EMBED: the group's (i, j) sequence indices, so that the residue fetch of the next pair is one dependent
     // load (idx byte) instead of two (pair table, then idx byte) - the second level did not fit one iteration
     constexpr int PIJ_CAP = 640;
-    __shared__ int16_t pij[EMBED ? 2 * PIJ_CAP : 2];
+    __shared__ __attribute__((aligned(16))) float lds_all[LDS_MST + LDS_RING + LDS_EMB + (EMBED ? PIJ_CAP : 0)];
+    float* const mst = lds_all;
+    float* const xring = lds_all + LDS_MST;
+    float* const emb = lds_all + LDS_MST + LDS_RING;
+    int16_t* const pij = reinterpret_cast<int16_t*>(lds_all + LDS_MST + LDS_RING + LDS_EMB);
     if (EMBED) {
         // both requests in flight before the first store (a load - wait - store loop costs one L2 round trip per step)
         constexpr int NV = 22 * 64 / 4;
@@ -1270,14 +1291,20 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     const int ts = lane >> 3, cl = lane & 7;
     const int per = (a.P + a.G - 1) / a.G;
 
-    float w[8][8];
+    // Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per issue slot).  This kernel has
+    // no MFMA beside which packed math would hurt (k_main's reason for -fno-slp-vectorize) and its VALU pipe was 80 %
+    // busy (PMC): every per-channel operation below works on pairs.
+    // Projection weights as pairs over the OUTPUTS (o, o + 1): pv(o, o + 1) += w2[o / 2][i] * d[i] keeps the
+    // per-output summation order over i, i.e. the bits of the scalar loop it replaces.
+    f32x2 w2[4][8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o)
+    for (int o = 0; o < 8; o += 2)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const f32x4 u = *reinterpret_cast<const f32x4*>(a.wqk + o * 64 + 8 * cl + 4 * q);
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.wqk + o * 64 + 8 * cl + 4 * q);
+            const f32x4 u1 = *reinterpret_cast<const f32x4*>(a.wqk + (o + 1) * 64 + 8 * cl + 4 * q);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) w[o][4 * q + i] = u[i];
+            for (int i = 0; i < 4; ++i) w2[o >> 1][4 * q + i] = f32x2{u0[i], u1[i]};
         }
     // after the transposing reduction lane cl holds projection cl (0-3: q', 4-7: k')
     const float bj = a.bqk[cl];
@@ -1298,18 +1325,19 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     const int p0 = a.fine ? gp0 + run * a.sub : gp0, p1 = a.fine ? min(gp1, p0 + a.sub) : gp1;
     if (p0 >= p1) return;       // a run past the end of the last group (k_colfin does not read its slot)
     const float vmask = lvalid ? 1.f : 0.f;
-    float z[4][8], s_acc = 0.f, zt[4][8], s_tot = 0.f;
+    f32x2 z[4][4], zt[4][4];          // Z~[h][8 channels of this lane] as channel pairs: the current run, the group so far
+    float s_acc = 0.f, s_tot = 0.f;
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { z[hh][i] = 0.f; zt[hh][i] = 0.f; }
+        for (int i = 0; i < 4; ++i) { z[hh][i] = f32x2{0.f, 0.f}; zt[hh][i] = f32x2{0.f, 0.f}; }
     auto fold = [&]() {         // group += run; run = 0
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 zt[hh][i] += z[hh][i];
-                z[hh][i] = 0.f;
+                z[hh][i] = f32x2{0.f, 0.f};
             }
         s_tot += s_acc; s_acc = 0.f;
     };
@@ -1333,6 +1361,32 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
             nx1[u] = *reinterpret_cast<const f32x4*>(a.x + tk * 64 + 8 * cl + 4);
         }
         nqr[u] = *reinterpret_cast<const f32x4*>(a.qrow + tk * 4);
+    };
+    // ---- the ring (RING > 0) ----
+    // slot of pair p: (p - p0) % RING.  Three requests per pair and wave: the lane's two 16-byte halves of its token row
+    // (destination = slot base + lane * 16, the layout each lane reads back), and q' as one dword per lane - lane j < 32
+    // fetches q'[site j >> 2][j & 3] (lanes 32..63 repeat them into the spare words) -> q'[8 sites][4] contiguous.
+    float* const wring = xring + (RING ? wave * RING * CS_SLOT : 0);
+    const int lq = min(chunk * 32 + wave * 8 + ((lane & 31) >> 2), a.Lloc - 1);      // the site whose q' this lane fetches
+    auto issue = [&](int p) {
+        const int pc = min(p, a.P - 1);                       // (past the end: a valid pair nobody uses)
+        const size_t row = ((size_t)b * a.P + pc) * a.Lloc;
+        float* dst = wring + ((p - p0) % RING) * CS_SLOT;
+        const float* xs = a.x + (row + lcl) * 64 + 8 * cl;
+        __builtin_amdgcn_global_load_lds(xs, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(xs + 4, dst + 256, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(a.qrow + (row + lq) * 4 + (lane & 3), dst + 512, 4, 0, 0);
+    };
+    // The ring is read with ds_read in asm: hipcc orders an ordinary LDS read behind EVERY outstanding global_load_lds
+    // it may alias (s_waitcnt vmcnt(0)), which would drain the ring once per iteration.  Loads return in issue order,
+    // so "at most 3 (RING - 2) requests outstanding" means the two oldest pairs have landed (later stores and staging
+    // requests only make the wait conservative).
+    auto take = [&](int p, int u) {
+        typedef __attribute__((address_space(3))) float* lds_ptr;
+        const unsigned base = (unsigned)(size_t)(lds_ptr)(wring + ((p - p0) % RING) * CS_SLOT);
+        const unsigned ax = base + lane * 16, aq = base + 2048 + ts * 16;
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(nx0[u]), "=&v"(nx1[u]), "=&v"(nqr[u]) : "v"(ax), "v"(aq) : "memory");
     };
     // EMBED: x0 of a pair is two table rows; its residues are requested two iterations ahead and the rows read
     // from LDS one iteration ahead (residue load -> LDS read -> use is a dependent chain: inside one iteration
@@ -1367,10 +1421,18 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
             __builtin_amdgcn_global_load_lds(src + min(i, n4 - 1), dst + (256 * k + 64 * wave) * 4, 16, 0, 0);
         }
     };
-    stage(p0, 0); fetch(p0, 0); fetch(p0 + 1, 1);
+    stage(p0, 0);
+    if (RING) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) issue(p0 + i);
+    } else {
+        fetch(p0, 0); fetch(p0 + 1, 1);
+    }
     if (EMBED) { fetch_idx(p0, 0); fetch_idx(p0 + 1, 1); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // (RING: only the staged matrices have to be there - they were requested first, the ring's requests stay in flight)
+    if (RING) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RING ? RING : 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
     if (EMBED) { lookup(0); lookup(1); fetch_idx(p0 + 2, 0); fetch_idx(p0 + 3, 1); }
     int buf = 0;
     for (int pt = p0; pt < p1; pt += 16, buf ^= 1) {
@@ -1381,50 +1443,70 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
       for (int p = pt; p < pe; p += 2) {
         const bool two = p + 1 < pe;                       // wave-uniform (an odd group end leaves one pair)
         f32x4 xv0[2], xv1[2], qr[2];
+        if (RING) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RING > 2 ? RING - 2 : 0)) : "memory");
+            take(p, 0); take(p + 1, 1);
+            issue(p + RING); issue(p + RING + 1);           // into the two slots just read
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) { qr[u] = nqr[u]; xv0[u] = nx0[u]; xv1[u] = nx1[u]; }
         if (EMBED) { lookup(0); lookup(1); fetch_idx(p + 4, 0); fetch_idx(p + 5, 1); }
-        fetch(p + 2, 0);
-        fetch(p + 3, 1);
-        float d[2][8], act[2];
+        if (!RING) {
+            fetch(p + 2, 0);
+            fetch(p + 3, 1);
+        }
+        f32x2 d[2][4];
+        float act[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             // (for a lone last pair the second chain recomputes the first pair's matrix row: finite, unused)
             const float* m = mt + (two ? (p + u - pt) : (p - pt)) * MROW + 8 * cl;
-            f32x4 y0 = br0, y1 = br1;
+            f32x2 y[4] = {f32x2{br0[0], br0[1]}, f32x2{br0[2], br0[3]}, f32x2{br1[0], br1[1]}, f32x2{br1[2], br1[3]}};
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
                 const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + hh * 64);
                 const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { y0[i] = fmaf(qr[u][hh], m0[i], y0[i]); y1[i] = fmaf(qr[u][hh], m1[i], y1[i]); }
+                const f32x2 qh = f32x2{qr[u][hh], qr[u][hh]};
+                y[0] = pk_fma(qh, f32x2{m0[0], m0[1]}, y[0]);
+                y[1] = pk_fma(qh, f32x2{m0[2], m0[3]}, y[1]);
+                y[2] = pk_fma(qh, f32x2{m1[0], m1[1]}, y[2]);
+                y[3] = pk_fma(qh, f32x2{m1[2], m1[3]}, y[3]);
             }
             // x' = x + row attention of this block (bias row included)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { d[u][i] = xv0[u][i] + y0[i]; d[u][4 + i] = xv1[u][i] + y1[i]; }
-            float sm = ((d[u][0] + d[u][1]) + (d[u][2] + d[u][3])) + ((d[u][4] + d[u][5]) + (d[u][6] + d[u][7]));
+            d[u][0] = f32x2{xv0[u][0], xv0[u][1]} + y[0];
+            d[u][1] = f32x2{xv0[u][2], xv0[u][3]} + y[1];
+            d[u][2] = f32x2{xv1[u][0], xv1[u][1]} + y[2];
+            d[u][3] = f32x2{xv1[u][2], xv1[u][3]} + y[3];
+            const f32x2 s2 = (d[u][0] + d[u][1]) + (d[u][2] + d[u][3]);
+            float sm = s2[0] + s2[1];
             sm += dpp_f<0x141>(sm);     // row_half_mirror: lane i <-> 7 - i
             sm += dpp_f<0x1B>(sm);      // quad reverse
             sm += dpp_f<0xB1>(sm);      // xor 1
             const float mean = sm * (1.f / 64.f);
-            float v = 0.f;
+            const f32x2 mean2 = f32x2{mean, mean};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { d[u][i] -= mean; v = fmaf(d[u][i], d[u][i], v); }
+            for (int i = 0; i < 4; ++i) d[u][i] -= mean2;
+            f32x2 v2 = d[u][0] * d[u][0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) v2 = pk_fma(d[u][i], d[u][i], v2);
+            float v = v2[0] + v2[1];
             v += dpp_f<0x141>(v);
             v += dpp_f<0x1B>(v);
             v += dpp_f<0xB1>(v);
             const float rstd = __builtin_amdgcn_rsqf(v * (1.f / 64.f) + LN_EPS);
+            const f32x2 rstd2 = f32x2{rstd, rstd};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) d[u][i] *= rstd;
-            // eight 64-long dot products: 8 channels per lane, then a transposing butterfly over the
-            // 8 lanes of the token (half mirror, quad reverse, xor 1)
+            for (int i = 0; i < 4; ++i) d[u][i] *= rstd2;
+            // eight 64-long dot products: 8 channels per lane (two outputs per packed FMA, channel after channel), then
+            // a transposing butterfly over the 8 lanes of the token (half mirror, quad reverse, xor 1)
             float pv[8];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                float acc = w[o][0] * d[u][0];
+            for (int o2 = 0; o2 < 4; ++o2) {
+                f32x2 acc = w2[o2][0] * f32x2{d[u][0][0], d[u][0][0]};
 #pragma unroll
-                for (int i = 1; i < 8; ++i) acc = fmaf(w[o][i], d[u][i], acc);
-                pv[o] = acc;
+                for (int i = 1; i < 8; ++i) acc = pk_fma(w2[o2][i], f32x2{d[u][i >> 1][i & 1], d[u][i >> 1][i & 1]}, acc);
+                pv[2 * o2] = acc[0];
+                pv[2 * o2 + 1] = acc[1];
             }
             // lane-bit-2 step without selects: two masked DPP adds per value pair (bank_mask picks the 4-lane groups
             // each is meant for; same operands and pairing as keep + dpp(send), see treduce_step4_masked)
@@ -1449,22 +1531,31 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
             // k'[hh] sits in lane 4 + hh of this token's 8-lane group
             const float k0 = swz<(4 << 5) | 0x18>(act[u]), k1 = swz<(5 << 5) | 0x18>(act[u]),
                         k2 = swz<(6 << 5) | 0x18>(act[u]), k3 = swz<(7 << 5) | 0x18>(act[u]);
+            const f32x2 kk[4] = {f32x2{k0, k0}, f32x2{k1, k1}, f32x2{k2, k2}, f32x2{k3, k3}};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                z[0][i] = fmaf(k0, d[u][i], z[0][i]);
-                z[1][i] = fmaf(k1, d[u][i], z[1][i]);
-                z[2][i] = fmaf(k2, d[u][i], z[2][i]);
-                z[3][i] = fmaf(k3, d[u][i], z[3][i]);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) z[hh][i] = pk_fma(kk[hh], d[u][i], z[hh][i]);
         }
         // runs of 8 pairs (short groups): the run boundary in the middle of a staged tile (fine = 0 only; wave-uniform)
         if (a.sub == 8 && !a.fine && p + 2 - pt == 8 && p + 2 < pe) fold();
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetches) have landed
-      __syncthreads();
+      if (RING) {
+          // the next tile's matrices were requested before this tile's ring traffic: once at most the ring's own
+          // requests are outstanding they have landed (in-order return) - the ring itself keeps flowing
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RING ? RING : 1)) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+      } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetches) have landed
+          __syncthreads();
+      }
       if (more && (pt + 16 - p0) % a.sub == 0) fold();    // a run boundary inside the group (fine = 0 only)
     }
     fold();
+    // (the ring's requests past the end of the walk are still in flight, bound for this block's LDS: they must land
+    // before the block gives its LDS back)
+    if (RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // every wave owns its sites: one partial per (b, g[, run], site), no cross-wave reduction
     if (lvalid) {
         const size_t slot = a.fine ? ((size_t)b * a.G + g) * a.S + run : (size_t)b * a.G + g;
@@ -1473,7 +1564,7 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
         for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                f32x4 u = {zt[hh][4 * q], zt[hh][4 * q + 1], zt[hh][4 * q + 2], zt[hh][4 * q + 3]};
+                f32x4 u = {zt[hh][2 * q][0], zt[hh][2 * q][1], zt[hh][2 * q + 1][0], zt[hh][2 * q + 1][1]};
                 *reinterpret_cast<f32x4*>(out + hh * 64 + 8 * cl + 4 * q) = u;
             }
         out[256 + cl] = s_tot;      // S_q[0..3] | S_k[0..3]

@@ -8,7 +8,9 @@
 // ctypes (GIL released), so the CLI's loader / writer threads scale with host cores.
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <cerrno>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -221,6 +223,177 @@ int64_t pf_format_phylip_n(const float* preds, int32_t n, const char* const* ids
     return format_phylip_impl(preds, n, ids, id_lens, out, cap);
 }
 
+}  // extern "C"
+
+// ---- neighbour joining + Newick text (the CLI's --trees: infer_alns.py:62-64,120-123) -------------------------------
+//
+// The reference calls skbio.tree.nj (not installed here); phyloformer_amd/nj.py is this build's pinned statement of
+// the algorithm (FastME -m N goldens, tests/test_treecmp.py) and THIS function is its native twin: the same float64
+// operations in the same order - numpy's pairwise row sums included - and Python's repr() of the branch lengths, so
+// that the .nj.nwk files are byte-identical to nj.py's (tests/test_host.py) while `-t` stays on the native file
+// pipeline (with `-t` every file used to fall back to per-file Python under the GIL).
+namespace {
+
+// numpy's add.reduce over a contiguous row (DOUBLE_pairwise_sum): < 8 sequential, <= 128 eight accumulators, else halves
+double np_pairwise_sum(const double* a, int64_t n) {
+    if (n < 8) {
+        double res = -0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// Python's repr(float): the shortest digits that round-trip, fixed notation for -4 < decimal point <= 16 (with ".0" for
+// integers), else d.ddde+XX with at least two exponent digits
+void append_repr(std::string& out, double x) {
+    if (x != x) { out += "nan"; return; }
+    if (x == INFINITY || x == -INFINITY) { out += x < 0 ? "-inf" : "inf"; return; }
+    char buf[64];
+    const auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX, shortest
+    const char* p = buf;
+    if (*p == '-') { out += '-'; ++p; }
+    char digits[32];
+    int nd = 0;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    int e10 = 0;
+    if (p < r.ptr && *p == 'e') {
+        ++p;
+        const bool neg = *p == '-';
+        if (*p == '-' || *p == '+') ++p;
+        for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
+        if (neg) e10 = -e10;
+    }
+    const int decpt = e10 + 1;
+    if (-4 < decpt && decpt <= 16) {
+        if (decpt <= 0) {
+            out += "0.";
+            out.append((size_t)(-decpt), '0');
+            out.append(digits, (size_t)nd);
+        } else if (decpt >= nd) {
+            out.append(digits, (size_t)nd);
+            out.append((size_t)(decpt - nd), '0');
+            out += ".0";
+        } else {
+            out.append(digits, (size_t)decpt);
+            out += '.';
+            out.append(digits + decpt, (size_t)(nd - decpt));
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) { out += '.'; out.append(digits + 1, (size_t)(nd - 1)); }
+        char ex[16];
+        const int e = decpt - 1;
+        snprintf(ex, sizeof ex, "e%c%02d", e < 0 ? '-' : '+', e < 0 ? -e : e);
+        out += ex;
+    }
+}
+
+// preds [n(n-1)/2] (pairs i < j, lexicographic) -> Newick text of the neighbour-joining tree, as nj.py writes it
+void nj_newick(const float* preds, int32_t n, const char* const* ids, const int64_t* id_lens, bool clamp, std::string& out) {
+    std::vector<std::string> labels((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        const char* id = ids[i] ? ids[i] : "";
+        labels[(size_t)i].assign(id, (size_t)(id_lens ? id_lens[i] : (int64_t)strlen(id)));
+    }
+    out.clear();
+    if (n == 1) { out = "(" + labels[0] + ");\n"; return; }
+    auto at = [&](int64_t i, int64_t j) -> double {      // the symmetric matrix vec_to_phylip builds (float32, dm + dm.T)
+        if (i == j) return 0.0;
+        if (i > j) { const int64_t t = i; i = j; j = t; }
+        return (double)(preds[i * n - i * (i + 1) / 2 + (j - i - 1)] + 0.0f);
+    };
+    if (n == 2) {
+        char num[64];
+        snprintf(num, sizeof num, "%.6g", at(0, 1) / 2);
+        out = "(" + labels[0] + ":" + num + "," + labels[1] + ":" + num + ");\n";
+        return;
+    }
+    auto fmt = [&](std::string& dst, double x) {
+        if (clamp && x < 0) x = 0.0;
+        append_repr(dst, x);
+    };
+    const size_t N = (size_t)n;
+    std::vector<double> d(N * N), sub, r, dn(N);
+    for (size_t i = 0; i < N; ++i)
+        for (size_t j = 0; j < N; ++j) d[i * N + j] = at((int64_t)i, (int64_t)j);
+    std::vector<int32_t> active((size_t)n);
+    for (int32_t i = 0; i < n; ++i) active[(size_t)i] = i;
+    while (active.size() > 3) {
+        const size_t m = active.size();
+        sub.resize(m * m);
+        r.resize(m);
+        for (size_t a = 0; a < m; ++a)
+            for (size_t b = 0; b < m; ++b) sub[a * m + b] = d[(size_t)active[a] * N + (size_t)active[b]];
+        for (size_t a = 0; a < m; ++a) r[a] = np_pairwise_sum(&sub[a * m], (int64_t)m);
+        // q = (m - 2) * sub - r[:, None] - r[None, :], diagonal = inf; the first minimum in row-major order (np.argmin)
+        const double mm2 = (double)((int64_t)m - 2);
+        double best = INFINITY;
+        size_t ba = 0, bb = 0;
+        bool have = false, saw_nan = false;
+        for (size_t a = 0; a < m && !saw_nan; ++a)
+            for (size_t b = 0; b < m; ++b) {
+                const double q = a == b ? INFINITY : (mm2 * sub[a * m + b] - r[a]) - r[b];
+                if (q != q) { ba = a; bb = b; saw_nan = true; have = true; break; }     // np.argmin: the first NaN wins
+                if (!have || q < best) { best = q; ba = a; bb = b; have = true; }
+            }
+        if (ba > bb) { const size_t t = ba; ba = bb; bb = t; }
+        const size_t ia = (size_t)active[ba], ib = (size_t)active[bb];
+        const double dab = sub[ba * m + bb];
+        const double la = 0.5 * dab + (r[ba] - r[bb]) / (double)(2 * ((int64_t)m - 2));
+        const double lb = dab - la;
+        std::string nl;
+        nl.reserve(labels[ia].size() + labels[ib].size() + 64);
+        nl += '('; nl += labels[ia]; nl += ':'; fmt(nl, la); nl += ','; nl += labels[ib]; nl += ':'; fmt(nl, lb); nl += ')';
+        for (size_t k = 0; k < N; ++k) dn[k] = 0.5 * ((d[ia * N + k] + d[ib * N + k]) - dab);
+        for (size_t k = 0; k < N; ++k) { d[ia * N + k] = dn[k]; d[k * N + ia] = dn[k]; }
+        d[ia * N + ia] = 0.0;
+        labels[ia].swap(nl);
+        std::string().swap(labels[ib]);
+        active.erase(active.begin() + (std::ptrdiff_t)bb);
+    }
+    const size_t i = (size_t)active[0], j = (size_t)active[1], k = (size_t)active[2];
+    const double li = 0.5 * ((d[i * N + j] + d[i * N + k]) - d[j * N + k]);
+    const double lj = 0.5 * ((d[i * N + j] + d[j * N + k]) - d[i * N + k]);
+    const double lk = 0.5 * ((d[i * N + k] + d[j * N + k]) - d[i * N + j]);
+    out.reserve(labels[i].size() + labels[j].size() + labels[k].size() + 96);
+    out += '('; out += labels[i]; out += ':'; fmt(out, li); out += ','; out += labels[j]; out += ':'; fmt(out, lj);
+    out += ','; out += labels[k]; out += ':'; fmt(out, lk); out += ");\n";
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pf_nj_newick_n(const float* preds, int32_t n, const char* const* ids, const int64_t* id_lens, int32_t clamp_negative,
+                       char* out, int64_t cap) {
+    if (!preds || n < 1 || !ids || !id_lens || (!out && cap > 0)) return PF_EINVAL;
+    for (int32_t i = 0; i < n; ++i) if (id_lens[i] < 0) return PF_EINVAL;
+    try {
+        std::string text;
+        nj_newick(preds, n, ids, id_lens, clamp_negative != 0, text);
+        if (out && (int64_t)text.size() <= cap) memcpy(out, text.data(), text.size());
+        return (int64_t)text.size();
+    } catch (...) { return PF_ENOMEM; }
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // ---- many files per call, on native threads (no GIL anywhere near the file system) ---------------------------
 //
 // The CLI's loop over a directory (infer_alns.py:97-117) opens, parses and writes one small file per
@@ -248,9 +421,11 @@ namespace {
 template <typename F>
 void run_pool(int32_t count, int32_t threads, F&& fn) {
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, count));
-    if (nt == 1) { for (int32_t i = 0; i < count; ++i) fn(i); return; }
+    if (nt == 1) { for (int32_t i = 0; i < count; ++i) { try { fn(i); } catch (...) {} } return; }
     std::atomic<int32_t> next{0};
-    auto work = [&] { for (int32_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
+    // (an exception that escaped a std::thread body would be std::terminate: the callers' lambdas record failures per
+    // item, and whatever they did not foresee ends here - ADVICE r05)
+    auto work = [&] { for (int32_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) { try { fn(i); } catch (...) {} } };
     std::vector<std::thread> pool;
     pool.reserve(nt);
     // the calling thread is one of the workers; a thread the system refuses to start (EAGAIN) only narrows the pool -
@@ -381,28 +556,38 @@ int pf_fasta_batch_gather(const pf_fasta_batch_t* const* batches, const int32_t*
 }
 
 int pf_phylip_write_batch(const pf_fasta_batch_t* const* batches, const int32_t* file_idx, int32_t count, int32_t n,
-                          const float* preds, const char* const* out_paths, int32_t threads, int32_t* status) {
+                          const float* preds, const char* const* out_paths, const char* const* tree_paths, int32_t threads,
+                          int32_t* status) {
     if (!batches || !file_idx || count < 0 || n < 2 || !preds || !out_paths || !status) return PF_EINVAL;
     for (int32_t k = 0; k < count; ++k) {
         const pf_fasta_batch* b = batches[k];
-        if (!b || !out_paths[k] || file_idx[k] < 0 || (size_t)file_idx[k] >= b->files.size()) return PF_EINVAL;
+        if (!b || !out_paths[k] || (tree_paths && !tree_paths[k]) || file_idx[k] < 0 || (size_t)file_idx[k] >= b->files.size())
+            return PF_EINVAL;
         const auto& f = b->files[(size_t)file_idx[k]];
         if (f.status != PF_OK || f.n != n) return PF_EINVAL;
     }
     const size_t P = (size_t)n * (size_t)(n - 1) / 2;
-    run_pool(count, threads, [&](int32_t k) {
-        try {
-            const auto& f = batches[k]->files[(size_t)file_idx[k]];
-            std::vector<const char*> ids((size_t)n);
-            std::vector<int64_t> lens((size_t)n);
-            for (int32_t i = 0; i < n; ++i) { ids[(size_t)i] = f.ids.data() + f.spans[2 * (size_t)i]; lens[(size_t)i] = f.spans[2 * (size_t)i + 1]; }
-            const float* p = preds + (size_t)k * P;
-            const int64_t need = format_phylip_impl(p, n, ids.data(), lens.data(), nullptr, 0);
-            std::string text((size_t)need, '\0');
-            format_phylip_impl(p, n, ids.data(), lens.data(), &text[0], need);
-            status[k] = write_file(out_paths[k], text.data(), text.size());
-        } catch (const std::bad_alloc&) { status[k] = -ENOMEM; }
-    });
+    try {       // (run_pool's own bookkeeping allocates: nothing may leave through the C ABI)
+        run_pool(count, threads, [&](int32_t k) {
+            try {
+                const auto& f = batches[k]->files[(size_t)file_idx[k]];
+                std::vector<const char*> ids((size_t)n);
+                std::vector<int64_t> lens((size_t)n);
+                for (int32_t i = 0; i < n; ++i) { ids[(size_t)i] = f.ids.data() + f.spans[2 * (size_t)i]; lens[(size_t)i] = f.spans[2 * (size_t)i + 1]; }
+                const float* p = preds + (size_t)k * P;
+                const int64_t need = format_phylip_impl(p, n, ids.data(), lens.data(), nullptr, 0);
+                if (need < 0) { status[k] = -EINVAL; return; }
+                std::string text((size_t)need, '\0');
+                format_phylip_impl(p, n, ids.data(), lens.data(), &text[0], need);
+                status[k] = write_file(out_paths[k], text.data(), text.size());
+                if (tree_paths && status[k] == 0) {             // <stem>.nj.nwk beside it (infer_alns.py:120-123)
+                    nj_newick(p, n, ids.data(), lens.data(), true, text);
+                    status[k] = write_file(tree_paths[k], text.data(), text.size());
+                }
+            } catch (const std::bad_alloc&) { status[k] = -ENOMEM; }
+            catch (...) { status[k] = -EIO; }
+        });
+    } catch (...) { return PF_ENOMEM; }
     return PF_OK;
 }
 

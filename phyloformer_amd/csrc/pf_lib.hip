@@ -169,6 +169,7 @@ struct pf_handle {
     float* pair_table = nullptr;  // [484][72] block-0 row-attention contributions per residue pair (k_embed)
     bool embed_mfma = false;      // option "embed_mfma": use k_main<MODE_FIRST> instead of k_embed (cross-check)
     int colstats_fine = -1;       // option "colstats_fine": k_colstats blocks per run (1) / per group (0) / by batch (-1)
+    bool colstats_ring = true;    // option "colstats_ring": x / q' of the next pairs through an LDS ring (1) or registers (0: cross-check)
     bool materialize_x0 = false;  // option "materialize_x0": k_embed writes x0 and block 0 reads it (round-1 path)
     float* first_consts = nullptr;  // consts for k_main<FIRST> (only bqk used)
     float* first_img = nullptr;     // LDS image for k_main<FIRST> (only the row-statistics tail used)
@@ -208,6 +209,12 @@ struct pf_handle {
     int tile_force = -1;
     // float64 path for ill-conditioned shapes (pf_precise.hip.h): option "precise" -1 = by shape, 0 = never, 1 = always
     int precise = -1;
+    // fp16 operand ranges of the default kernels, from the checkpoint (check_f16_ranges): false = this checkpoint's
+    // weights could overflow an fp16 MFMA operand, every forward takes the float64 kernels; f16_vmax_col = bound of the
+    // column attention's |v| (the column-apply operand is <= P * f16_vmax_col / 16)
+    bool f16_ok = true;
+    double f16_vmax_col = 0.0;
+    char f16_why[160] = {0};
     bool precise_ffn_valu = false;   // option "precise_ffn_valu": the float64 FFN on the VALU instead of the matrix cores (cross-check)
     PreciseWeights pw;
     char* wsp = nullptr; size_t wsp_bytes = 0;
@@ -262,6 +269,54 @@ AttnHost take_attn(Blob& bl) {
     return a;
 }
 
+// fp16 operand ranges (pf_device.hip.h): the split MFMA operands must stay below 65504.  LayerNorm output is bounded
+// by construction (|x~| <= sqrt(63), ||x~||_2 <= 8); everything else by the checkpoint's weights:
+//   hidden   2 a |W1' x~ + b1'| <= 2 (||W1' a row||_2 * 8 + |b1' a|)           (gelu_scaled returns at most 2 |x|)
+//   M_base   sum_d |Wo[c][16h+d]| * (||Wv' row||_2 * 8 + |bv'|), times <= 64    (k_rowfin's a_scale, L_total <= 2^20)
+//   column   q' / mean(q') * |v| / 16 <= P * vmax_col / 16                       (checked per shape, f16_range_ok)
+// The five shipped checkpoints sit at 61 / 196 / 30 (P = 19,900 gives 37,600).  A checkpoint outside the range is not
+// refused: its forwards run on the float64 kernels (use_precise).
+struct F16Ranges { double hidden = 0, mbase = 0, vmax_col = 0, wmax = 0; };
+void f16_note_attn(const std::vector<float>& wv, const std::vector<float>& bv, const float* wo, bool col, F16Ranges* r) {
+    double vmax[E];
+    for (int hd = 0; hd < E; ++hd) {
+        double n2 = 0;
+        for (int c = 0; c < E; ++c) { n2 += (double)wv[(size_t)hd * E + c] * wv[(size_t)hd * E + c]; r->wmax = std::max(r->wmax, std::fabs((double)wv[(size_t)hd * E + c])); }
+        vmax[hd] = std::sqrt(n2) * 8.0 + std::fabs((double)bv[hd]);
+        if (col) r->vmax_col = std::max(r->vmax_col, vmax[hd]);
+    }
+    for (int c = 0; c < E; ++c)
+        for (int hh = 0; hh < NH; ++hh) {
+            double m = 0;
+            for (int d = 0; d < HD; ++d) { m += std::fabs((double)wo[(size_t)c * E + 16 * hh + d]) * vmax[16 * hh + d]; r->wmax = std::max(r->wmax, std::fabs((double)wo[(size_t)c * E + 16 * hh + d]) * (col ? COLAPPLY_A_SCALE : 1.0)); }
+            if (!col) r->mbase = std::max(r->mbase, m);
+        }
+}
+void f16_note_ffn(const std::vector<float>& w1a, const std::vector<float>& b1a, const std::vector<float>& w2s, F16Ranges* r) {
+    for (int j = 0; j < FF; ++j) {
+        double n2 = 0;
+        for (int c = 0; c < E; ++c) { n2 += (double)w1a[(size_t)j * E + c] * w1a[(size_t)j * E + c]; r->wmax = std::max(r->wmax, std::fabs((double)w1a[(size_t)j * E + c])); }
+        r->hidden = std::max(r->hidden, 2.0 * (std::sqrt(n2) * 8.0 + std::fabs((double)b1a[j])));
+    }
+    for (float v : w2s) r->wmax = std::max(r->wmax, std::fabs((double)v));
+}
+constexpr double F16_LIMIT = 60000.0;            // (65504 with a margin for the rounding of the bounds themselves)
+void check_f16_ranges(pf_handle* h, const F16Ranges& r) {
+    h->f16_vmax_col = r.vmax_col;
+    const bool finite = std::isfinite(r.hidden) && std::isfinite(r.mbase) && std::isfinite(r.vmax_col) && std::isfinite(r.wmax);
+    h->f16_ok = !PF_F16 || (finite && r.hidden < F16_LIMIT && r.mbase * 64.0 < F16_LIMIT && r.wmax < F16_LIMIT);
+    if (!h->f16_ok)
+        snprintf(h->f16_why, sizeof h->f16_why, "fp16 operand bounds: hidden %.3g, row-mix base %.3g, weights %.3g (limit %.0f)",
+                 r.hidden, r.mbase * 64.0, r.wmax, F16_LIMIT);
+}
+// per forward: the column-apply operand q' / mean(q') * v / 16 <= P * vmax_col / 16, and q' / mean(q') <= L_total on
+// the row side is covered up to 2^20 sites by k_rowfin's b_scale
+bool f16_range_ok(const pf_handle* h, int N, int L_total) {
+    if (!PF_F16) return true;
+    const double P = (double)N * (N - 1) / 2;
+    return h->f16_ok && P * h->f16_vmax_col * COLAPPLY_B_SCALE < F16_LIMIT && L_total <= (1 << 20);
+}
+
 int prepare_weights(pf_handle* h, const pf_weights_t* w) {
     Blob bl{w->blob};
     const float* emb_w = bl.take((size_t)E * NA);
@@ -299,6 +354,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         build_pair_table(table.data(), rows[0], ptab);
         if ((rc = upload(h, ptab, &h->pair_table))) return rc;
     }
+    F16Ranges ranges;
     std::vector<std::vector<float>> row_bqk(nb);
     std::vector<std::vector<uint16_t>> row_tail(nb);
     for (int k = 0; k < nb; ++k) {
@@ -310,6 +366,9 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         fold(r.wq, r.bq, r.g, r.b, NH, E, wq, bq);
         fold(r.wk, r.bk, r.g, r.b, NH, E, wk, bk);
         fold(r.wv, r.bv, r.g, r.b, E, E, wv, bv);
+        f16_note_attn(wv, bv, r.wo, false, &ranges);
+        for (float v : wq) ranges.wmax = std::max(ranges.wmax, std::fabs((double)v));
+        for (float v : wk) ranges.wmax = std::max(ranges.wmax, std::fabs((double)v));
         row_tail[k].assign((size_t)(FRAG_END - FRAG_WV) * 8, 0);
         std::vector<uint16_t> wvlo((size_t)WVLO_FRAGS * 8);
         pack_row_stats(wv.data(), wq.data(), wk.data(), row_tail[k].data(), wvlo.data());
@@ -328,6 +387,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         fold(c.wq, c.bq, c.g, c.b, NH, E, cwq, cbq);
         fold(c.wk, c.bk, c.g, c.b, NH, E, cwk, cbk);
         fold(c.wv, c.bv, c.g, c.b, E, E, cwv, cbv);
+        f16_note_attn(cwv, cbv, c.wo, true, &ranges);
         std::vector<float> wqk((size_t)8 * E), bqk(8);
         std::copy(cwq.begin(), cwq.end(), wqk.begin());
         std::copy(cwk.begin(), cwk.end(), wqk.begin() + 4 * E);
@@ -352,6 +412,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         for (auto& v : b1f) v = (float)((double)v * alpha);
         std::vector<float> w2s((size_t)E * FF);
         for (size_t i = 0; i < w2s.size(); ++i) w2s[i] = (float)((double)ffn[k].w2[i] / alpha * 0.5);   // gelu_scaled returns 2*a*gelu
+        f16_note_ffn(w1f, b1f, w2s, &ranges);
         std::vector<uint16_t> img((size_t)FRAG_END * 8);
         pack_frags(w1f.data(), FF, E, FF, img.data() + (size_t)FRAG_W1 * 8);
         pack_frags(w2s.data(), E, FF, E, img.data() + (size_t)FRAG_W2 * 8);
@@ -371,6 +432,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
     std::copy(row_bqk[0].begin(), row_bqk[0].end(), cst0.begin() + CONST_BQK);
     std::vector<uint16_t> img0((size_t)FRAG_END * 8, 0);
     std::copy(row_tail[0].begin(), row_tail[0].end(), img0.begin() + (size_t)FRAG_WV * 8);
+    check_f16_ranges(h, ranges);
     if ((rc = upload(h, img0, &h->first_img))) return rc;
     return upload(h, cst0, &h->first_consts);
 }
@@ -644,9 +706,11 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         ProfScope ps(h, K_COLSTATS);
         const unsigned nblk = (unsigned)(B * a.nchunks * w.nparts());
         if (k == 0 && x0_on_the_fly(h))
-            hipLaunchKernelGGL(k_colstats<true>, dim3(nblk), dim3(256), 0, h->cur, a);
+            hipLaunchKernelGGL((k_colstats<true, 0>), dim3(nblk), dim3(256), 0, h->cur, a);
+        else if (h->colstats_ring)
+            hipLaunchKernelGGL((k_colstats<false, PF_CS_RING>), dim3(nblk), dim3(256), 0, h->cur, a);
         else
-            hipLaunchKernelGGL(k_colstats<false>, dim3(nblk), dim3(256), 0, h->cur, a);
+            hipLaunchKernelGGL((k_colstats<false, 0>), dim3(nblk), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     {
@@ -813,10 +877,15 @@ int chunk_batch(pf_handle* h, int B, int P, int Lloc) {
 
 // Grow-only workspaces that no longer fit the budget together are released before a chunk is laid out
 // (a one-stream call may have left `ws` sized for a whole chunk that now runs as two halves).
+// The float64 path's workspace (wsp) counts too: a handle that alternates large default-path and large float64
+// shapes would otherwise hold ws + ws2 + wsp, twice the budget - whichever path runs next releases what
+// the other left behind when the three together exceed the budget.
 int trim_workspaces(pf_handle* h, size_t need_total) {
-    if (h->ws_bytes + h->ws2_bytes <= std::max(need_total, (size_t)h->ws_limit_bytes)) return PF_OK;
+    if (h->ws_bytes + h->ws2_bytes + h->wsp_bytes <= std::max(need_total, (size_t)h->ws_limit_bytes)) return PF_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+    if (h->wsp) { hipFree(h->wsp); h->wsp = nullptr; h->wsp_bytes = 0; }
+    if (h->ws_bytes + h->ws2_bytes <= std::max(need_total, (size_t)h->ws_limit_bytes)) return PF_OK;
     if (h->ws) { hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
     if (h->ws2) { hipFree(h->ws2); h->ws2 = nullptr; h->ws2_bytes = 0; }
     return PF_OK;
@@ -1083,6 +1152,7 @@ int pf_set_option(pf_handle_t* h, const char* key, int64_t value) {
     else if (k == "reserve_cus") h->reserve_cus = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128));
     else if (k == "ablate") h->ablate = (int)value;
     else if (k == "force_rccl") h->force_rccl = value != 0;
+    else if (k == "colstats_ring") h->colstats_ring = value != 0;
     else if (k == "precise") h->precise = value < 0 ? -1 : (value != 0);
     else if (k == "precise_ffn_valu") h->precise_ffn_valu = value != 0;
     else if (k == "phase_prof") {
@@ -1256,6 +1326,11 @@ int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap)
         for (int i = 0; i < 8 && i < cap; ++i) dst[i] = (float)((double)v[i] * 1e-6);   // mega-cycles
         return 8;
     }
+    if (std::strcmp(name, "f16_ranges") == 0) {       // [checkpoint inside the fp16 operand ranges, bound of the column |v|]
+        if (dst && cap > 0) dst[0] = h->f16_ok ? 1.f : 0.f;
+        if (dst && cap > 1) dst[1] = (float)h->f16_vmax_col;
+        return 2;
+    }
     auto it = h->taps.find(name);
     if (it == h->taps.end()) return fail(h, PF_ESTATE, "no tap '%s' (set debug_keep=1 and run a forward)", name);
     const int64_t n = (int64_t)it->second.size();
@@ -1265,7 +1340,14 @@ int64_t pf_debug_read(pf_handle_t* h, const char* name, float* dst, int64_t cap)
 
 int pf_device_info(pf_handle_t* h, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes) {
     if (!h) return PF_EINVAL;
-    if (name_out && name_cap) snprintf(name_out, name_cap, "%s (%s)", h->prop.name, h->prop.gcnArchName);
+    if (name_out && name_cap) {
+        // (the pool's boxes report an empty marketing name: fall back to hipDeviceGetName, then to the architecture)
+        char nm[256] = {0};
+        snprintf(nm, sizeof nm, "%s", h->prop.name);
+        if (!nm[0] && hipDeviceGetName(nm, (int)sizeof nm, h->device) != hipSuccess) nm[0] = 0;
+        if (!nm[0]) snprintf(nm, sizeof nm, "AMD GPU");
+        snprintf(name_out, name_cap, "%s (%s)", nm, h->prop.gcnArchName);
+    }
     if (cu_count) *cu_count = h->prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = h->prop.totalGlobalMem;
     return PF_OK;

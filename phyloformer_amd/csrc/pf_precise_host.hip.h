@@ -11,28 +11,23 @@
 // path from (N, L_total) alone, so all ranks issue the same sequence).
 
 // Which alignments take the float64 path: a function of the alignment's global shape only (never of the batch).
-//   L_total < PRECISE_MAX_SITES : rows shorter than two 32-site tiles of k_main.  The distance is a MEAN over sites;
-//                                 with few sites the rounding errors of the split-bf16 products do not average out.
-//                                 Measured (profiles/r05_precise_sweep.txt, r05_adversarial_study.txt, the soak of
-//                                 tests/test_gpu_precise.py): every case over 1e-4 in the round-4 soaks had <= 7 sites;
-//                                 simulated alignments of 20-32 sites reach 6e-5 ... 1.05e-4, of 33-48 sites 8e-5, of
-//                                 >= 100 sites <= 2.3e-5.
-//   N <= PRECISE_MAX_SEQS       : 2-4 sequences (1-6 pairs): the column attention normalises by sums of 1-6 terms;
-//                                 errors of 1e-4 ... 3e-4 up to 64 sites
-//   P * L_total < PRECISE_MAX_TOKENS : small alignments of any proportion: 5 x 33 ... 6 x 64 reach 3e-4, and the tail is
-//                                 long - one gapped 7 x 65 alignment in 960 soak cases of other seeds sat at 2.0e-4
-//                                 (profiles/r05l_soak_seeds.txt).  Below 8,192 tokens float64 costs < 0.2 ms.
-// Alignments this rule keeps on the default kernels hold 1e-4 when they look like alignments (simulated, gapped,
-// up to 35 % of the residues randomised: <= 8e-5, section 5 of DESIGN.md); uniformly random residues, two-letter
-// alphabets or all-gap columns do not at any size (2e-4 ... 3e-3, where the fp32 reference itself is up to 2.6e-3 from
-// float64) - option "precise" = 1 / `infer_alns.py --precise always` computes those in float64.
-constexpr int PRECISE_MAX_SITES = 64;
-constexpr int PRECISE_MAX_SEQS = 4;
-constexpr long PRECISE_MAX_TOKENS = 8192;
+//   L_total < PRECISE_MAX_SITES : rows shorter than one 32-site tile of k_main.  The distance is a MEAN over sites, and
+//                                 on a handful of sites the forward is ill-conditioned in fp32 itself: the fp32 reference
+//                                 is 3e-5 ... 8e-4 from its own float64 evaluation there (distances of 20-50), and no
+//                                 fp32-level implementation can promise to sit within 1e-4 of ANOTHER fp32-level
+//                                 implementation - both are a rounding cloud around the exact value.  float64 sits at the
+//                                 cloud's centre: its distance from the reference is the reference's own error.
+// Round 6 (fp16 operand split): the default kernels now round at fp32's own level (their distance from float64 equals
+// the fp32 reference's, profiles/r06_precise_sweep.txt), so the rule shrank from "< 64 sites, <= 4 sequences or
+// < 8,192 tokens" (round 5: the split-bf16 products' 2^-17 per operand did not average out on small alignments) to rows
+// shorter than a tile: with the float64 path off, the sweep's 2,115 cases leave 24 over max(1e-4, 2 x the fp32
+// reference's own error), all with <= 24 sites (round 5: 300+, up to 200 sites).
+constexpr int PRECISE_MAX_SITES = 32;
 bool use_precise(const pf_handle* h, int N, int L_total) {
+    // above the option: an alignment / checkpoint whose operands could overflow fp16 never reaches the default kernels
+    if (!f16_range_ok(h, N, L_total)) return true;
     if (h->precise >= 0) return h->precise != 0;
-    const long P = (long)N * (N - 1) / 2;
-    return L_total < PRECISE_MAX_SITES || N <= PRECISE_MAX_SEQS || P * L_total < PRECISE_MAX_TOKENS;
+    return L_total < PRECISE_MAX_SITES;
 }
 
 // ---- weights widened to double, transposed for lane = channel access -----------------------------------
@@ -144,6 +139,14 @@ int ensure_precise_workspace(pf_handle* h, int B, int P, int Lloc, PWorkspace* w
     const size_t need = precise_bytes(B, P, Lloc, off);
     if (need > h->wsp_bytes) {
         if (h->wsp) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->wsp); h->wsp = nullptr; h->wsp_bytes = 0; }
+        // the default path's workspaces give way when the three would not fit the budget together (trim_workspaces
+        // does the same for this one from the other side)
+        if (h->ws_bytes + h->ws2_bytes + need > std::max(need, (size_t)h->ws_limit_bytes)) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+            if (h->ws) { hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
+            if (h->ws2) { hipFree(h->ws2); h->ws2 = nullptr; h->ws2_bytes = 0; }
+        }
         HIPCHK(h, hipMalloc((void**)&h->wsp, need));
         h->wsp_bytes = need;
     }

@@ -17,7 +17,7 @@ from .weights import ModelWeights
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libphyloformer_amd.so")
-ABI_VERSION = 4            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
+ABI_VERSION = 5            # PF_ABI_VERSION of include/phyloformer_amd.h this binding was written against
 UNIQUE_ID_BYTES = 256      # PF_UNIQUE_ID_BYTES: two ncclUniqueIds, one per communicator / stream
 
 PF_OK, PF_EINVAL, PF_EHIP, PF_ERCCL, PF_ENOMEM, PF_ESTATE = 0, -1, -2, -3, -4, -5
@@ -93,8 +93,9 @@ SIGNATURES = {
     "pf_fasta_batch_infos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_fasta_batch_id": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "pf_fasta_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pf_nj_newick_n": (C.c_int64, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]),
     "pf_phylip_write_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                        C.POINTER(C.c_char_p), C.c_int32, C.c_void_p]),
+                                        C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_void_p]),
     "pf_forward_shards_emulated": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_void_p]),
 }

@@ -95,6 +95,25 @@ def format_phylip(preds: np.ndarray, ids: Sequence[str]) -> bytes:
     return buf.raw[:w]
 
 
+def nj_newick(preds: np.ndarray, ids: Sequence[str], clamp_negative: bool = True) -> bytes:
+    """Distance vector ``[P]`` + ids → Newick text of the neighbour-joining tree (utf-8 bytes), byte-identical to
+    ``nj.neighbor_joining`` on the matrix ``vec_to_phylip`` builds (the CLI's ``--trees``, infer_alns.py:120-123)."""
+    lib = load_library()
+    n = len(ids)
+    p = np.ascontiguousarray(np.asarray(preds, dtype=np.float32).reshape(-1))
+    if p.size != n * (n - 1) // 2:
+        raise ValueError(f"expected {n * (n - 1) // 2} distances for {n} sequences, got {p.shape}")
+    enc = [s.encode("utf8") for s in ids]
+    arr = (C.c_char_p * n)(*enc)
+    lens = np.array([len(e) for e in enc], dtype=np.int64)
+    need = lib.pf_nj_newick_n(p.ctypes.data, n, arr, lens.ctypes.data, int(clamp_negative), None, 0)
+    if need < 0:
+        raise RuntimeError(f"pf_nj_newick_n failed with status {need}")
+    buf = C.create_string_buffer(int(need) + 1)
+    w = lib.pf_nj_newick_n(p.ctypes.data, n, arr, lens.ctypes.data, int(clamp_negative), buf, need)
+    return buf.raw[:w]
+
+
 class FastaBatch:
     """``pf_fasta_batch_load``: a list of FASTA files read and parsed on native threads (GIL released for the
     whole call).  The parsed alignments stay in library memory; ``gather`` copies the residue indices of a
@@ -158,8 +177,9 @@ def gather(entries: Sequence[Tuple["FastaBatch", int]], n: int, l: int) -> np.nd
 
 
 def write_phylip(entries: Sequence[Tuple["FastaBatch", int]], n: int, preds: np.ndarray, out_paths: Sequence[str],
-                 threads: int = 8) -> None:
-    """Format ``preds[B, P]`` and write ``out_paths`` on native threads; ``OSError`` for the first file that failed."""
+                 threads: int = 8, tree_paths: "Sequence[str] | None" = None) -> None:
+    """Format ``preds[B, P]`` and write ``out_paths`` - and, with ``tree_paths``, the neighbour-joining trees of the same
+    distances - on native threads; ``OSError`` for the first file that failed."""
     lib = load_library()
     k = len(entries)
     p = np.ascontiguousarray(np.asarray(preds, dtype=np.float32).reshape(k, -1))
@@ -168,11 +188,16 @@ def write_phylip(entries: Sequence[Tuple["FastaBatch", int]], n: int, preds: np.
     hs = (C.c_void_p * k)(*[e[0]._h for e in entries])
     fi = np.array([e[1] for e in entries], dtype=np.int32)
     paths = (C.c_char_p * k)(*[os.fsencode(q) for q in out_paths])
+    trees = None
+    if tree_paths is not None:
+        if len(tree_paths) != k:
+            raise ValueError(f"expected {k} tree paths")
+        trees = (C.c_char_p * k)(*[os.fsencode(q) for q in tree_paths])
     status = np.zeros(k, dtype=np.int32)
-    rc = lib.pf_phylip_write_batch(hs, fi.ctypes.data, k, n, p.ctypes.data, paths, int(threads), status.ctypes.data)
+    rc = lib.pf_phylip_write_batch(hs, fi.ctypes.data, k, n, p.ctypes.data, paths, trees, int(threads), status.ctypes.data)
     if rc != 0:
         raise ValueError(f"pf_phylip_write_batch: status {rc}")
     bad = np.flatnonzero(status)
     if bad.size:
         e = -int(status[bad[0]])
-        raise OSError(e, os.strerror(e), out_paths[int(bad[0])])
+        raise OSError(e, os.strerror(e), out_paths[int(bad[0])] if tree_paths is None else f"{out_paths[int(bad[0])]} / {tree_paths[int(bad[0])]}")

@@ -132,10 +132,13 @@ class DirectoryRunner:
 
     def _write(self, path: str, pred: np.ndarray, ids: List[str]):
         stem = Path(path).stem
-        if self.native_io and not self.trees:
-            from .hostio import format_phylip
+        if self.native_io:
+            from .hostio import format_phylip, nj_newick
             with open(os.path.join(self.out_dir, f"{stem}.phy"), "wb") as fh:
                 fh.write(format_phylip(pred, ids))
+            if self.trees:                         # (infer_alns.py:120-123)
+                with open(os.path.join(self.out_dir, f"{stem}.nj.nwk"), "wb") as fh:
+                    fh.write(nj_newick(pred, ids))
             return
         from .phylip import vec_to_phylip
         dm, text = vec_to_phylip(pred, ids)
@@ -180,12 +183,15 @@ class DirectoryRunner:
             self.stats["write_wait_s"] += time.perf_counter() - t0
 
     def _write_native(self, n: int, group: list, preds: np.ndarray):
-        """``<stem>.phy`` of a whole launch: formatted and written on native threads (infer_alns.py:105-117)."""
+        """``<stem>.phy`` - and with ``--trees`` ``<stem>.nj.nwk`` - of a whole launch: formatted (the trees: joined) and
+        written on native threads (infer_alns.py:105-123)."""
         from .hostio import write_phylip
         outs = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.phy") for g in group]
+        trees = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.nj.nwk") for g in group] if self.trees else None
         # (at most 4 threads: creating files in ONE directory from 8 / 16 threads is a lock convoy on the directory -
         # 4,096 outputs took 0.98 / 1.19 s instead of 0.01 s, profiles/r05c_cli_bench.txt)
-        write_phylip([g[1] for g in group], n, preds, outs, min(self.io_threads, 4))
+        # (with trees the neighbour joining - O(N^3) per file - is most of the work: all I/O threads)
+        write_phylip([g[1] for g in group], n, preds, outs, min(self.io_threads, 4) if trees is None else self.io_threads, trees)
 
     def _gpu_worker(self, engine, jobs: "queue.Queue", writers, pending, errors: list):
         while True:
@@ -224,7 +230,7 @@ class DirectoryRunner:
             for w in workers:
                 w.start()
             try:
-                feed = self._feed_native if (self.native_io and not self.trees) else self._feed_python
+                feed = self._feed_native if self.native_io else self._feed_python
                 bad = feed(paths, loaders, jobs, errors)
                 deferred = bad or deferred         # a file that fails to parse sits in front of a bad extension
             finally:

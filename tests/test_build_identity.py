@@ -23,7 +23,7 @@ def test_build_info_of_the_product_library():
     from phyloformer_amd import build, engine
     build.build()
     info = engine.build_info()
-    assert info["abi"] == engine.ABI_VERSION == 4 and info["arch"] == "gfx950"
+    assert info["abi"] == engine.ABI_VERSION == 5 and info["arch"] == "gfx950"
     assert info["sched_strategy"] == "iterative-ilp" and info["sched_fallback"] is False
     assert "amdgpu-sched-strategy=iterative-ilp" in info["flags"]["pf_lib.hip"]
     assert "sched-strategy" not in info["flags"]["pf_precise.hip"]          # its own unit: hipcc crashes on it otherwise

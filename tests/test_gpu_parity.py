@@ -125,7 +125,7 @@ def test_tiny_taps_localise_every_kernel(engines, weights, golden):
 @pytest.mark.parametrize("precise", [0, -1])
 def test_oracle_parity_small_shapes(engines, weights, precise):
     """Seeded synthetic alignments incl. ragged tile tails, gaps and the minimum sizes - through the default kernels
-    (precise = 0: their edge cases) and as the product routes them (-1: the first four take the float64 path)."""
+    (precise = 0: their edge cases) and as the product routes them (-1: the first two - fewer than 32 sites - take the float64 path)."""
     e = engines("pf_indel", precise=precise)
     w = weights("pf_indel").tensors
     for (n, l, gaps, seed) in [(2, 1, False, 1), (3, 31, False, 2), (4, 32, True, 3), (5, 33, True, 4),
@@ -300,7 +300,7 @@ def test_two_stream_schedule_same_bits(weights, golden):
 
 
 def test_permutation_equivariance(engines):
-    e = engines("pf", precise=0)        # the default kernels (9 x 70 is float64 territory as routed)
+    e = engines("pf", precise=0)        # the default kernels (option pinned: the test sweeps their tilings)
     idx = simulate_batch(1, 9, 70, seed=21)[0]
     base = e.forward(idx)
     rng = np.random.default_rng(0)
@@ -318,8 +318,12 @@ def test_errors_mirror_reference(engines):
         e.forward(np.zeros((201, 8), np.uint8))                      # model.py:24-28
     with pytest.raises(ValueError, match="outside 0..21"):
         e.forward(np.full((3, 8), 22, np.uint8))
-    with pytest.raises(ValueError):
+    # one sequence = no pair: the reference's forward fails in attention.py:193 with this RuntimeError
+    # (tests/golden/cli_bad_entry.json, from the real CLI); the C ABI itself answers PF_EINVAL for N < 2
+    with pytest.raises(RuntimeError, match=r"cannot reshape tensor of 0 elements into shape \[1, -1, 0, 64\]"):
         e.forward(np.zeros((1, 8), np.uint8))
+    out = np.zeros(4, np.float32)
+    assert e._lib.pf_forward(e._h, np.zeros((1, 8), np.uint8).ctypes.data, 1, 1, 8, out.ctypes.data) == -1
     e.set_option("max_seqs", 0)                                      # opt-in: lift the cap
     try:
         assert e.forward(np.zeros((201, 2), np.uint8)).shape == (201 * 200 // 2,)
@@ -338,7 +342,7 @@ def test_table_embedding_equals_mfma_embedding(engines, golden):
     """Block 0's row statistics come from a host-built residue-pair table (k_embed); the MFMA
     formulation it replaced (k_main<MODE_FIRST>, option "embed_mfma") must give the same taps and
     the same distances."""
-    e = engines("pf_indel", precise=0)      # the default kernels' block 0 (9 x 75 is float64 territory as routed)
+    e = engines("pf_indel", precise=0)      # the default kernels' block 0 (option pinned)
     rng = np.random.default_rng(12)
     idx = rng.integers(0, 22, (2, 9, 75)).astype(np.uint8)          # all 22 symbols incl. X and gap
     taps = {}
@@ -521,3 +525,24 @@ def test_full_size_properties(engines, ck, n, l, gaps):
         both = e.forward(np.stack([other[0], idx, other[1]]))
         assert np.array_equal(both[1], base)                               # batch invariance, bitwise
     assert float(np.abs(e.forward_shards_emulated(idx, 8) - base).max()) <= 2e-5 * scale
+
+
+def test_colstats_ring_prefetch_is_bit_identical_to_register_prefetch(engines, golden):
+    """Round 6: k_colstats<false, RING> moves the token rows and q' of the next pairs global -> LDS (global_load_lds
+    into a per-wave ring, counted s_waitcnt vmcnt) instead of through registers; the arithmetic and its order are the
+    register variant's (option colstats_ring = 0), so every bit must agree: batched and alone (groups / runs), ragged
+    site chunks, short groups, a shape whose last chunk holds one site."""
+    e = engines("pf", precise=0)
+    g = golden("configs.npz")
+    rng = np.random.default_rng(77)
+    cases = [g["c3_idx"][:3], g["c3_idx"][:1], g["c2_idx"], rng.integers(0, 22, (2, 9, 65)).astype(np.uint8),
+             rng.integers(0, 20, (1, 33, 40)).astype(np.uint8), rng.integers(0, 20, (5, 7, 97)).astype(np.uint8)]
+    try:
+        for idx in cases:
+            e.set_option("colstats_ring", 1)
+            ring = e.forward(idx)
+            e.set_option("colstats_ring", 0)
+            regs = e.forward(idx)
+            assert np.isfinite(ring).all() and np.array_equal(ring, regs), idx.shape
+    finally:
+        e.set_option("colstats_ring", 1)

@@ -154,6 +154,20 @@ def test_native_bulk_io_equals_python_io(tmp_path):
             outs[native] = {f: (out / f).read_bytes() for f in sorted(os.listdir(out))}
         assert len(outs[True]) == 40 and outs[True] == outs[False]
         assert outs[True]["x00.phy"].startswith(b"4\nseq 0 of 0 0.0000000000 ")
+        # --trees stays on the native pipeline (round 6: pf_phylip_write_batch joins and writes <stem>.nj.nwk as well):
+        # the same bytes as the per-file Python path (phylip.vec_to_phylip + nj.neighbor_joining)
+        trees = {}
+        for native in (True, False):
+            out = tmp_path / f"tree{int(native)}"
+            out.mkdir()
+            r = scheduler.DirectoryRunner([FakeEngine(), FakeEngine()], str(out), io_threads=3, native_io=native, trees=True)
+            fed = []
+            r._feed_native = (lambda *a, _f=r._feed_native: fed.append(1) or _f(*a))
+            assert r.run(paths)["alignments"] == 40 and bool(fed) == native
+            trees[native] = {f: (out / f).read_bytes() for f in sorted(os.listdir(out))}
+        assert len(trees[True]) == 80 and trees[True] == trees[False]
+        assert all(trees[True][f] == outs[True][f] for f in outs[True])
+        assert trees[True]["x00.nj.nwk"].startswith(b"(") and trees[True]["x00.nj.nwk"].endswith(b");\n")
     finally:
         scheduler.FILES_PER_LOAD = old
 

@@ -1,5 +1,5 @@
 """End-to-end CLI throughput: write K synthetic FASTA files, run infer_alns.py on the directory.
-    python tools/cli_bench.py [--n 256] [--seqs 60] [--sites 500] [--extra "--batch 1 --python-io"]"""
+    python tools/cli_bench.py [--n 256] [--seqs 60] [--sites 500] [--trees] [--extra "--batch 1 --python-io"]"""
 import argparse, json, os, shutil, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,7 @@ ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--seqs", type=int, default=60)
 ap.add_argument("--sites", type=int, default=500)
 ap.add_argument("--extra", default="")
+ap.add_argument("--trees", action="store_true", help="pass -t: <stem>.nj.nwk beside every <stem>.phy")
 a = ap.parse_args()
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tmp = tempfile.mkdtemp(prefix="pfcli_")
@@ -25,10 +26,10 @@ for k in range(a.n):
             fh.write(b">taxon_%d\n" % i + lut[row].tobytes() + b"\n")
 t0 = time.perf_counter()
 r = subprocess.run([sys.executable, os.path.join(repo, "infer_alns.py"), os.path.join(repo, "models/pf.ckpt"),
-                    ind, "-o", outd, "--bench", *a.extra.split()], capture_output=True, text=True)
+                    ind, "-o", outd, "--bench", *(["-t"] if a.trees else []), *a.extra.split()], capture_output=True, text=True)
 wall = time.perf_counter() - t0
 rep = [l for l in r.stderr.splitlines() if l.startswith("{")]
-print(json.dumps({"files": a.n, "shape": [a.seqs, a.sites], "extra": a.extra, "process_wall_s": round(wall, 3),
+print(json.dumps({"files": a.n, "shape": [a.seqs, a.sites], "trees": a.trees, "extra": a.extra, "process_wall_s": round(wall, 3),
                   "returncode": r.returncode, "report": json.loads(rep[-1]) if rep else r.stderr[-500:]}))
-assert len(os.listdir(outd)) == a.n
+assert len(os.listdir(outd)) == a.n * (2 if a.trees else 1)
 shutil.rmtree(tmp)

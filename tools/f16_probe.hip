@@ -61,6 +61,12 @@ __global__ void k_split(const float* in, unsigned* out, int n) {
     else if (NOPS == 0)
         asm volatile("v_dot2c_f32_f16 %0, %2, %4\n\tv_dot2c_f32_f16 %1, %3, %4\n\ts_nop 0\n\tv_mul_f32 %1, 1.0, %1\n\tv_mul_f32 %0, 1.0, %0"
                      : "+v"(r0), "+v"(r1) : "s"(0x0000bc00u), "s"(0xbc000000u), "v"(hb));
+    else if (NOPS == 1)
+        asm volatile("v_dot2c_f32_f16 %0, %2, %4\n\tv_dot2c_f32_f16 %1, %3, %4\n\ts_nop 1\n\tv_mul_f32 %1, 1.0, %1\n\tv_mul_f32 %0, 1.0, %0"
+                     : "+v"(r0), "+v"(r1) : "s"(0x0000bc00u), "s"(0xbc000000u), "v"(hb));
+    else if (NOPS == 2)     // the production pattern of split8: the LAST dot2c, then s_nop 1, then the reader of ITS result
+        asm volatile("v_dot2c_f32_f16 %0, %2, %4\n\tv_dot2c_f32_f16 %1, %3, %4\n\ts_nop 1\n\tv_mul_f32 %0, 1.0, %0\n\tv_mul_f32 %1, 1.0, %1"
+                     : "+v"(r0), "+v"(r1) : "s"(0x0000bc00u), "s"(0xbc000000u), "v"(hb));
     else
         asm volatile("v_dot2c_f32_f16 %0, %2, %4\n\tv_dot2c_f32_f16 %1, %3, %4\n\ts_nop 3\n\tv_mul_f32 %1, 1.0, %1\n\tv_mul_f32 %0, 1.0, %0"
                      : "+v"(r0), "+v"(r1) : "s"(0x0000bc00u), "s"(0xbc000000u), "v"(hb));
@@ -135,9 +141,9 @@ struct Rsmi {
 };
 
 template <bool F16>
-void power_run(Rsmi& smi, const char* name, double seconds, const u32x4* d_frags, float* d_out) {
+void power_run(Rsmi& smi, const char* name, double seconds, const u32x4* d_frags, float* d_out, int grid = 256) {
     const int iters = 4096;
-    auto launch = [&] { hipLaunchKernelGGL((k_mfma_power<F16>), dim3(256), dim3(512), 0, 0, d_frags, d_out, iters); };
+    auto launch = [&] { hipLaunchKernelGGL((k_mfma_power<F16>), dim3(grid), dim3(512), 0, 0, d_frags, d_out, iters); };
     launch(); hipDeviceSynchronize();
     const double j0 = smi.joules();
     const auto t0 = std::chrono::steady_clock::now();
@@ -145,9 +151,9 @@ void power_run(Rsmi& smi, const char* name, double seconds, const u32x4* d_frags
     do { for (int i = 0; i < 4; ++i) launch(); hipDeviceSynchronize(); n += 4;
          dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } while (dt < seconds);
     const double j1 = smi.joules();
-    const double mfmas = 256.0 * 8 * iters * 24 * n;                    // wave-level MFMA instructions
-    printf("power %-28s %7.1f W  %7.3f nJ/MFMA  %6.1f TFLOP/s (32x32x16: 32768 flop)  (%ld launches, %.2f s)\n", name,
-           (j1 - j0) / dt, (j1 - j0) / mfmas * 1e9, mfmas * 32768.0 / dt * 1e-12, n, dt);
+    const double mfmas = (double)grid * 8 * iters * 24 * n;             // wave-level MFMA instructions
+    printf("power %-44s grid %3d %7.1f W  %7.3f nJ/MFMA  %6.1f TFLOP/s  %6.2f ns per MFMA and SIMD  (%ld launches, %.2f s)\n", name, grid,
+           (j1 - j0) / dt, (j1 - j0) / mfmas * 1e9, mfmas * 32768.0 / dt * 1e-12, dt * 1e9 / ((double)iters * 24 * 2 * n), n, dt);
 }
 
 int main(int argc, char** argv) {
@@ -178,10 +184,12 @@ int main(int argc, char** argv) {
         hipMalloc((void**)&di, n * 4); hipMalloc((void**)&dou, (size_t)3 * n * 4);
         hipMemcpy(di, in.data(), n * 4, hipMemcpyHostToDevice);
         std::vector<unsigned> out((size_t)3 * n);
-        for (int nops = -1; nops <= 1; ++nops) {
+        for (int nops = -1; nops <= 3; ++nops) {
             if (nops < 0) hipLaunchKernelGGL(k_split<-1>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
             else if (nops == 0) hipLaunchKernelGGL(k_split<0>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
-            else hipLaunchKernelGGL(k_split<1>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
+            else if (nops == 1) hipLaunchKernelGGL(k_split<1>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
+            else if (nops == 2) hipLaunchKernelGGL(k_split<2>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
+            else hipLaunchKernelGGL(k_split<3>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
             hipMemcpy(out.data(), dou, out.size() * 4, hipMemcpyDeviceToHost);
             long bad_cvt = 0, bad_dot = 0, bad_rec = 0, sub_hi = 0, finite = 0;
             double worst_rel = 0, worst_abs = 0;
@@ -205,7 +213,7 @@ int main(int argc, char** argv) {
                 }
             printf("%s (reader %s): cvt_pk vs host RNE mismatches %ld / %d;  dot2c != sub: %ld;  hi+lo outside max(2^-22|g|, 2^-25): %ld "
                    "(worst rel %.3g = 2^%.2f for |g| >= 1/8, worst abs %.3g = 2^%.2f below; %ld subnormal hi among %ld finite)\n",
-                   nops < 0 ? "B/C/D" : "  C  ", nops < 0 ? "back to back" : nops == 0 ? "after s_nop 0" : "after s_nop 3", bad_cvt, n, bad_dot, bad_rec,
+                   nops < 0 ? "B/C/D" : "  C  ", nops < 0 ? "back to back" : nops == 0 ? "after s_nop 0" : nops == 1 ? "after s_nop 1, last result first" : nops == 2 ? "after s_nop 1, as split8 reads" : "after s_nop 3", bad_cvt, n, bad_dot, bad_rec,
                    worst_rel, std::log2(worst_rel), worst_abs, std::log2(worst_abs), sub_hi, finite);
         }
     }
@@ -235,6 +243,34 @@ int main(int argc, char** argv) {
         }
         power_run<true>(smi, "fp16 MFMA on the bf16 bit patterns", seconds, db, dout);
         power_run<false>(smi, "bf16 MFMA on the fp16 bit patterns", seconds, dh, dout);
+        // Do subnormal lo limbs cost the matrix pipe time or energy?  The same operands times 2^10 (every limb normal),
+        // full chip (power-capped) and on 16 CUs (far below the cap: the pipe's own rate).
+        std::vector<uint16_t> fs(fh.size());
+        {
+            std::mt19937_64 g2(11);
+            std::normal_distribution<float> nd2(0.f, 1.f);
+            for (int grp = 0; grp < 2; ++grp)
+                for (int s = 0; s < 4; ++s)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const float v = nd2(g2) * (grp == 0 ? 0.15f : 1.f) * 1024.f;
+                            const size_t hi_at = (((size_t)(2 * grp) * 4 + s) * 64 + lane) * 8 + i, lo_at = (((size_t)(2 * grp + 1) * 4 + s) * 64 + lane) * 8 + i;
+                            const uint16_t hh = f2h(v);
+                            fs[hi_at] = hh; fs[lo_at] = f2h(v - h2f(hh));
+                        }
+        }
+        u32x4* ds; hipMalloc((void**)&ds, fs.size() * 2);
+        hipMemcpy(ds, fs.data(), fs.size() * 2, hipMemcpyHostToDevice);
+        long nsub = 0, nsub_s = 0;
+        for (size_t i = 0; i < fh.size(); ++i) { nsub += (fh[i] & 0x7c00) == 0 && (fh[i] & 0x3ff); nsub_s += (fs[i] & 0x7c00) == 0 && (fs[i] & 0x3ff); }
+        printf("subnormal operand values: %ld of %zu as packed, %ld of %zu after scaling by 2^10\n", nsub, fh.size(), nsub_s, fs.size());
+        for (int rep = 0; rep < 2; ++rep) {
+            power_run<true>(smi, "fp16 hi/lo as packed (lo mostly subnormal)", seconds, dh, dout);
+            power_run<true>(smi, "fp16 hi/lo x 2^10 (all limbs normal)", seconds, ds, dout);
+        }
+        power_run<true>(smi, "fp16 hi/lo as packed", seconds / 2, dh, dout, 16);
+        power_run<true>(smi, "fp16 hi/lo x 2^10", seconds / 2, ds, dout, 16);
+        power_run<false>(smi, "bf16 hi/lo", seconds / 2, db, dout, 16);
     }
     return 0;
 }

@@ -11,7 +11,11 @@ from phyloformer_amd.msa_sim import simulate_batch
 w = load_weights("models/pf.ckpt")
 for B in (16, 1):
     idx = np.ascontiguousarray(np.resize(simulate_batch(min(B, 8), 60, 500, seed=3), (B, 60, 500)))
-    e = Engine(w, 0); e.forward(idx)
+    e = Engine(w, 0)
+    e.set_option("two_streams", 0)          # one stream: a launch covers the whole batch and has the chip to itself
+    for kv in os.environ.get("PF_AB_OPTIONS", "").split():      # e.g. PF_AB_OPTIONS="colstats_ring=0"
+        k, v = kv.split("="); e.set_option(k, int(v))
+    e.forward(idx)
     e.set_option("profile", 1); e.profile_reset()
     for _ in range(3): e.forward(idx)
     n, ms = e.profile_get(sys.argv[1])
