@@ -41,7 +41,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  ``value`` is the 
 in HBM when the timed region starts (the task statement: the PCIe-inclusive rate "is never `value`");
 ``value_pcie_inclusive`` is the same step through ``pf_forward`` with host buffers (H2D of the indices, D2H of
 the distances, one synchronisation per call) - the rate SURVEY.md 8d words its metric on.  Extra objects:
-``roofline`` (dominant kernel ``k_main``: algorithmic flops / HIP-event time vs the dense bf16 MFMA peak),
+``roofline`` (dominant kernel ``k_main``: algorithmic flops / HIP-event time vs the dense bf16 / fp16 MFMA peak),
 ``configs`` (N = 1: the other BASELINE configurations, a few hundred ms each), ``cpu_baseline`` (torch
 op-order port of the reference on this host's cores; N = 1, rank 0 only) and ``power`` (socket power / clock
 / energy read in-process from librocm_smi64 during the timed regions).
@@ -64,7 +64,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 (the same rate)
 HBM_PEAK_TBS = 8.0
 # algorithmic flops per token per k_main launch (MAC = 2 flops):
 #   FFN 64->256->64 = 65,536; column out_proj 64x64 = 8,192; next block's row v/q/k
@@ -691,7 +691,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
                     "schedule": "second timed region of the same steps with the batch on one stream (a launch covers "
                                 "the whole batch and has the chip to itself); `value` is the default two-stream schedule"
                                 if not args.one_stream else "one stream (--one-stream)",
-                    "note": "algorithmic flops (1 pass); the split-bf16 scheme issues 3 MFMA passes, "
+                    "note": "algorithmic flops (1 pass); the split-fp16 scheme issues 3 MFMA passes, "
                             "so frac tops out at 1/3"}
         metric, workload = workload_label(N, L, args.ckpt)
         line = {
@@ -699,7 +699,7 @@ def run(args, rank, world, local_rank, group, make_engine, weights, out=sys.stdo
             "value": round(value, 3), "unit": "alignments/s", "n_gpus": n_devices, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3-split MFMA, fp32 accumulate/residual", "data": "synthetic",
+            "dtype": "f16x3-split MFMA (two fp16 limbs per operand, 3 passes), fp32 accumulate/residual", "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": B if args.shard == "sites" else B * world,
                        "n_seqs": N, "n_sites": L, "parallelism": how,

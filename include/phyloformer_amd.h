@@ -95,7 +95,7 @@ int pf_abi_version(void);
 const char* pf_build_info(void);
 
 /* Create a handle on HIP device `device`: uploads the weights, builds the
- * embedding table and the bf16 hi/lo MFMA operand images.  Fails with PF_EHIP
+ * embedding table and the fp16 hi/lo MFMA operand images.  Fails with PF_EHIP
  * if no gfx950 device is present: there is no CPU fallback. */
 int pf_create(const pf_weights_t* w, int device, pf_handle_t** out);
 int pf_destroy(pf_handle_t* h);
@@ -121,12 +121,12 @@ const char* pf_last_error(const pf_handle_t* h);
  *   "embed_mfma" int   1 = compute block 0's row statistics with the MFMA kernel (k_main<FIRST>) instead of
  *                      the residue-pair table lookup (k_embed); cross-check only, same results to fp32 noise
  *   "precise"    int   which alignments take the float64 path (csrc/pf_precise.hip.h): -1 (default) = chosen from
- *                      the alignment's shape (fewer than 64 sites, at most 4 sequences, or fewer than 8192
- *                      pair-site tokens: the distance is a mean over sites, and with few of them the rounding of
- *                      the split-bf16 products does not average out below 1e-4), 0 = never, 1 = always (any
- *                      shape in float64: for input that is nothing like an alignment - uniformly random
- *                      residues, all-gap columns - where the default kernels reach 2e-4 ... 3e-3; 3-9 x slower).
- *                      The choice never depends on the batch.
+ *                      the alignment's shape (fewer than 32 sites or 8,192 pair-site tokens: the distance is a mean over sites, and on a
+ *                      handful of them the fp32 reference itself is 3e-5 ... 8e-4 from its float64 evaluation, so no
+ *                      fp32-level kernel can promise 1e-4 against it), 0 = never, 1 = always (any shape in float64;
+ *                      3-9 x slower).  The choice never depends on the batch.  Above the option: a checkpoint or
+ *                      shape whose operands could overflow the default kernels' fp16 MFMA operands (weights ~ 1000 x
+ *                      the trained ones, more than 2^20 sites) always runs in float64.
  */
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
 

@@ -62,10 +62,9 @@ def build_parser():
                         help="engines (HIP streams, one host thread each) per GPU; 2 hides the host-side gaps "
                              "of a synchronous forward, 1 = one launch sequence at a time")
     parser.add_argument("--precise", choices=["auto", "always", "never"], default="auto",
-                        help="float64 kernels: auto = for alignments of fewer than 64 sites, at most 4 sequences or fewer "
-                             "than 8192 pair-site tokens (where the fp32 reference itself is ill-conditioned); always = every "
-                             "alignment (input that is nothing like an alignment - random residues, all-gap columns -; "
-                             "3-9 x slower); never = the split-bf16 MFMA kernels on every shape")
+                        help="float64 kernels: auto = for alignments of fewer than 32 sites or 8,192 pair-site tokens (where the fp32 reference itself is "
+                             "ill-conditioned); always = every alignment (3-9 x slower); never = the split-fp16 MFMA kernels "
+                             "on every shape")
     parser.add_argument("--python-io", action="store_true",
                         help="use the pure-Python FASTA parser and PHYLIP writer instead of the native ones")
     parser.add_argument("--worker", default=None, help=argparse.SUPPRESS)   # "r/W": share r of W of the files

@@ -1257,17 +1257,21 @@ constexpr int CS_SLOT = 2 * 256 + 64;       // floats per ring slot: 8 sites x 6
 #ifndef PF_CS_RING
 #define PF_CS_RING 4
 #endif
-template <bool EMBED, int RING>
+#ifndef PF_CS_MT
+#define PF_CS_MT 16          // pair matrices per staging buffer of the ring variant
+#endif
+template <bool EMBED, int RING, int MT>
 #ifndef PF_CS_WAVES
 #define PF_CS_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     static_assert(!(EMBED && RING), "block 0 reads residue bytes, not x");
     static_assert(RING % 2 == 0, "pairs are consumed two at a time");
+    static_assert(MT == 16 || MT == 8, "pair matrices are staged 16 or 8 at a time (runs are multiples of 8)");
     // ONE LDS object (hipcc, ROCm 7.2: with a second __shared__ object it orders every ds_read behind every outstanding
     // global_load_lds - s_waitcnt vmcnt(0) - and the ring below would drain once per iteration; cdna_hip_programming.md):
-    //   two staging buffers of 16 pair matrices (4 x 64 floats each) | the ring | block 0: embedding table, pair indices
-    constexpr int LDS_MST = 2 * 16 * MROW, LDS_RING = RING ? 4 * RING * CS_SLOT : 0, LDS_EMB = EMBED ? 22 * 64 : 0;
+    //   two staging buffers of MT pair matrices (4 x 64 floats each) | the ring | block 0: embedding table, pair indices
+    constexpr int LDS_MST = 2 * MT * MROW, LDS_RING = RING ? 4 * RING * CS_SLOT : 0, LDS_EMB = EMBED ? 22 * 64 : 0;
     // EMBED: the group's (i, j) sequence indices, so that the residue fetch of the next pair is one dependent
     // load (idx byte) instead of two (pair table, then idx byte) - the second level did not fit one iteration
     constexpr int PIJ_CAP = 640;
@@ -1413,10 +1417,10 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     // wave-uniform base + lane * 16), no staging registers
     auto stage = [&](int pt, int buf) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.mrow + ((size_t)b * a.P + pt) * MROW);
-        const int n4 = min(16, p1 - pt) * (MROW / 4);
-        float* dst = mst + (size_t)buf * 16 * MROW;
+        const int n4 = min(MT, p1 - pt) * (MROW / 4);
+        float* dst = mst + (size_t)buf * MT * MROW;
 #pragma unroll
-        for (int k = 0; k < 16 * MROW / 4 / 256; ++k) {
+        for (int k = 0; k < MT * MROW / 4 / 256; ++k) {
             const int i = (int)threadIdx.x + 256 * k;
             __builtin_amdgcn_global_load_lds(src + min(i, n4 - 1), dst + (256 * k + 64 * wave) * 4, 16, 0, 0);
         }
@@ -1435,11 +1439,11 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     if (RING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
     if (EMBED) { lookup(0); lookup(1); fetch_idx(p0 + 2, 0); fetch_idx(p0 + 3, 1); }
     int buf = 0;
-    for (int pt = p0; pt < p1; pt += 16, buf ^= 1) {
-      const bool more = pt + 16 < p1;
-      if (more) stage(pt + 16, buf ^ 1);                   // lands during this tile's compute
-      const float* mt = mst + (size_t)buf * 16 * MROW;
-      const int pe = min(pt + 16, p1);
+    for (int pt = p0; pt < p1; pt += MT, buf ^= 1) {
+      const bool more = pt + MT < p1;
+      if (more) stage(pt + MT, buf ^ 1);                   // lands during this tile's compute
+      const float* mt = mst + (size_t)buf * MT * MROW;
+      const int pe = min(pt + MT, p1);
       for (int p = pt; p < pe; p += 2) {
         const bool two = p + 1 < pe;                       // wave-uniform (an odd group end leaves one pair)
         f32x4 xv0[2], xv1[2], qr[2];
@@ -1550,7 +1554,7 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the staged tile (and the last prefetches) have landed
           __syncthreads();
       }
-      if (more && (pt + 16 - p0) % a.sub == 0) fold();    // a run boundary inside the group (fine = 0 only)
+      if (more && (pt + MT - p0) % a.sub == 0) fold();    // a run boundary inside the group (fine = 0 only)
     }
     fold();
     // (the ring's requests past the end of the walk are still in flight, bound for this block's LDS: they must land

@@ -706,11 +706,11 @@ int phase_block(pf_handle* h, const ShardRun& r, int k, RowStats rs) {
         ProfScope ps(h, K_COLSTATS);
         const unsigned nblk = (unsigned)(B * a.nchunks * w.nparts());
         if (k == 0 && x0_on_the_fly(h))
-            hipLaunchKernelGGL((k_colstats<true, 0>), dim3(nblk), dim3(256), 0, h->cur, a);
+            hipLaunchKernelGGL((k_colstats<true, 0, 16>), dim3(nblk), dim3(256), 0, h->cur, a);
         else if (h->colstats_ring)
-            hipLaunchKernelGGL((k_colstats<false, PF_CS_RING>), dim3(nblk), dim3(256), 0, h->cur, a);
+            hipLaunchKernelGGL((k_colstats<false, PF_CS_RING, PF_CS_MT>), dim3(nblk), dim3(256), 0, h->cur, a);
         else
-            hipLaunchKernelGGL((k_colstats<false, 0>), dim3(nblk), dim3(256), 0, h->cur, a);
+            hipLaunchKernelGGL((k_colstats<false, 0, 16>), dim3(nblk), dim3(256), 0, h->cur, a);
         HIPCHK(h, hipGetLastError());
     }
     {
@@ -1037,7 +1037,8 @@ static int open_device(int device, pf_handle** out) {
     pf_handle* h = new pf_handle();
     if (const char* e = getenv("PF_TWO_STREAMS")) h->two_streams = atoi(e) != 0;   // A/B runs of whole programs
     if (getenv("PF_ROW_TILES")) h->tile_force = 0;          // read once: the tiling (and with it the layout of
-    if (getenv("PF_FLAT_TILES")) h->tile_force = 1;         // spart / outpart) cannot change between two calls
+    if (getenv("PF_FLAT_TILES")) h->tile_force = 1;
+    if (const char* v = getenv("PF_COLSTATS_RING")) h->colstats_ring = atoi(v) != 0;   // A/B and counter runs (tools/pmc_colstats.sh)         // spart / outpart) cannot change between two calls
     h->device = device;
     int rc = PF_OK;
     do {

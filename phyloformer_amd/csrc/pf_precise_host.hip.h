@@ -19,15 +19,22 @@
 //                                 cloud's centre: its distance from the reference is the reference's own error.
 // Round 6 (fp16 operand split): the default kernels now round at fp32's own level (their distance from float64 equals
 // the fp32 reference's, profiles/r06_precise_sweep.txt), so the rule shrank from "< 64 sites, <= 4 sequences or
-// < 8,192 tokens" (round 5: the split-bf16 products' 2^-17 per operand did not average out on small alignments) to rows
+// < 8,192 tokens" to "< 32 sites or < 8,192 tokens" (round 5: the split-bf16 products' 2^-17 per operand did not average out on small alignments) to rows
 // shorter than a tile: with the float64 path off, the sweep's 2,115 cases leave 24 over max(1e-4, 2 x the fp32
 // reference's own error), all with <= 24 sites (round 5: 300+, up to 200 sites).
+//   P * L_total < PRECISE_MAX_TOKENS : kept from round 5 for tiny alignments of any proportion.  Where the reference's
+//                                 own error is near 5e-5 an fp32-level result is over "2 x the reference's own error" by
+//                                 chance now and then (one 5 x 33 alignment of random residues in 2,880 soak cases of
+//                                 other seeds under the site rule alone: 1.13e-4 against 1.01e-4,
+//                                 profiles/r06g_soak_seeds.txt); below 8,192 tokens float64 costs < 0.2 ms.
 constexpr int PRECISE_MAX_SITES = 32;
+constexpr long PRECISE_MAX_TOKENS = 8192;
 bool use_precise(const pf_handle* h, int N, int L_total) {
     // above the option: an alignment / checkpoint whose operands could overflow fp16 never reaches the default kernels
     if (!f16_range_ok(h, N, L_total)) return true;
     if (h->precise >= 0) return h->precise != 0;
-    return L_total < PRECISE_MAX_SITES;
+    const long P = (long)N * (N - 1) / 2;
+    return L_total < PRECISE_MAX_SITES || P * L_total < PRECISE_MAX_TOKENS;
 }
 
 // ---- weights widened to double, transposed for lane = channel access -----------------------------------

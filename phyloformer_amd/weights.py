@@ -2,7 +2,7 @@
 
 The blob is the only weight format the native library sees
 (``pf_weights_t`` in ``include/phyloformer_amd.h``).  Everything derived from it
-— the ReLU'd embedding table, bf16 hi/lo splits, MFMA operand permutations —
+— the ReLU'd embedding table, fp16 hi/lo splits, MFMA operand permutations —
 is produced inside ``pf_create`` on the host.
 
 Tensor names and shapes follow the reference ``state_dict``

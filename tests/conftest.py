@@ -46,7 +46,7 @@ def engines(weights):
 
     def get(name="pf", precise=-1):
         """precise: -1 = the product's choice (float64 kernels for ill-conditioned shapes, csrc/pf_precise.hip.h);
-        0 = the default split-bf16 kernels on every shape - what the tests of their tile / group / shard edge
+        0 = the default split-fp16 kernels on every shape - what the tests of their tile / group / shard edge
         cases at small sizes want."""
         if (name, precise) not in cache:
             cache[name, precise] = Engine(weights(name), device=0)

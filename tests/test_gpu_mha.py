@@ -1,7 +1,8 @@
 """-m gpu: softmax MultiHeadAttention kernels (csrc/pf_mha.hip.h) against the reference class
 (goldens) and the oracle.  Tolerance: 5e-5 absolute on outputs of magnitude ~1 — every contraction
-is split-bf16 x3 (2^-16 relative) with fp32 softmax; the reference's own fp32 evaluation differs
-from fp64 by up to 1e-5 on the peaked case."""
+is split-fp16 x3 (two fp16 limbs per operand, 2^-22 relative; rounds 1-5: bf16 limbs, with three terms /
+six passes on the Q-K path) with fp32 softmax; the reference's own fp32 evaluation differs from fp64 by
+up to 1e-5 on the peaked case."""
 import numpy as np
 import pytest
 

@@ -23,7 +23,7 @@ def test_shards_match_unsharded_and_reference(engines, golden, nshards):
 
 @pytest.mark.parametrize("precise", [0, -1])
 def test_ragged_and_empty_shards(engines, precise):
-    # precise = 0: the default kernels' shard edge cases; -1: as routed (shapes of fewer than 32 sites take the float64 path)
+    # precise = 0: the default kernels' shard edge cases; -1: as routed (both shapes take the float64 path)
     e = engines("pf_indel", precise=precise)
     idx = simulate_batch(2, 6, 37, seed=5, gaps=True)  # 37 sites over 8 ranks: 5,5,...,2
     full = e.forward(idx)                              # 6 sequences: distances reach ~6 here

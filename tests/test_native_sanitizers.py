@@ -1,7 +1,7 @@
 """AddressSanitizer + UBSan build of the native HOST code, fuzzed.
 
 ``csrc/pf_hostio.cpp`` parses untrusted files in place of /root/reference/phyloformer/data.py:11-31 and writes the
-PHYLIP text of infer_alns.py:14-25; ``csrc/pf_host_prep.h`` is the host half of the engine (bf16 fragment packing,
+PHYLIP text of infer_alns.py:14-25; ``csrc/pf_host_prep.h`` is the host half of the engine (fp16 fragment packing,
 LayerNorm folding, the residue-pair table, the shape-only launch plans).  Both are plain C++: this test compiles them
 with ``g++ -fsanitize=address,undefined -fno-sanitize-recover`` into a test-only library and drives it with
 hypothesis from a child process that has libasan preloaded (``tests/native/fuzz_host.py``): truncated files, CR/LF,

@@ -6,7 +6,7 @@
 Prints one line per case and writes them as JSON (default gpurun_out/configs.json; the copy that is judged
 lives in profiles/r<NN>_configs.json).  `frac_mfma` / `frac_hbm` are the whole-forward roofline fractions of
 SURVEY.md section 8d: 602,240 algorithmic flop and 3,328 algorithmic bytes per token against 2.5 PFLOP/s
-dense bf16 and 8 TB/s (the split-bf16 scheme issues three MFMA passes, so frac_mfma tops out at 1/3).
+dense bf16 and 8 TB/s (the split-fp16 scheme issues three MFMA passes, so frac_mfma tops out at 1/3).
 """
 import json
 import os
