@@ -1372,25 +1372,31 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     // fetches q'[site j >> 2][j & 3] (lanes 32..63 repeat them into the spare words) -> q'[8 sites][4] contiguous.
     float* const wring = xring + (RING ? wave * RING * CS_SLOT : 0);
     const int lq = min(chunk * 32 + wave * 8 + ((lane & 31) >> 2), a.Lloc - 1);      // the site whose q' this lane fetches
-    auto issue = [&](int p) {
+    auto issue = [&](int p, size_t lane_off) {
         const int pc = min(p, a.P - 1);                       // (past the end: a valid pair nobody uses)
         const size_t row = ((size_t)b * a.P + pc) * a.Lloc;
         float* dst = wring + ((p - p0) % RING) * CS_SLOT;
-        const float* xs = a.x + (row + lcl) * 64 + 8 * cl;
+        const float* xs = a.x + row * 64 + lane_off;          // lane_off = (site of the lane) * 64 + 8 * (lane & 7)
         __builtin_amdgcn_global_load_lds(xs, dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(xs + 4, dst + 256, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(a.qrow + (row + lq) * 4 + (lane & 3), dst + 512, 4, 0, 0);
     };
-    // The ring is read with ds_read in asm: hipcc orders an ordinary LDS read behind EVERY outstanding global_load_lds
-    // it may alias (s_waitcnt vmcnt(0)), which would drain the ring once per iteration.  Loads return in issue order,
-    // so "at most 3 (RING - 2) requests outstanding" means the two oldest pairs have landed (later stores and staging
-    // requests only make the wait conservative).
+    const size_t lane_off0 = (size_t)lcl * 64 + 8 * cl;
+    // Reading the ring.  With all LDS in one object hipcc does not order ordinary LDS reads behind outstanding
+    // global_load_lds requests, so these are plain loads the scheduler may place and wait for like any other (an asm
+    // block with its own lgkmcnt(0) exposed the LDS latency twice per iteration); what orders them behind the DATA is the
+    // counted s_waitcnt vmcnt in front of them (asm volatile with a memory clobber: nothing moves across it).  Loads
+    // return in issue order, so "at most 3 (RING - 2) requests outstanding" means the two oldest pairs have landed
+    // (later stores and staging requests only make the wait conservative).  The two slots are refilled in the same
+    // iteration, and a refill must not land before the reads above have been SERVED (eight waves share the CU's LDS
+    // queue; a request that hits in L2 is back in a few hundred cycles): the address of the refill is made to depend on
+    // the six vectors just read (an empty asm that consumes them), so hipcc waits for exactly those reads - the pair
+    // matrices it requested meanwhile stay in flight - before it can issue the refill.
     auto take = [&](int p, int u) {
-        typedef __attribute__((address_space(3))) float* lds_ptr;
-        const unsigned base = (unsigned)(size_t)(lds_ptr)(wring + ((p - p0) % RING) * CS_SLOT);
-        const unsigned ax = base + lane * 16, aq = base + 2048 + ts * 16;
-        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(nx0[u]), "=&v"(nx1[u]), "=&v"(nqr[u]) : "v"(ax), "v"(aq) : "memory");
+        const float* slot = wring + ((p - p0) % RING) * CS_SLOT;
+        nx0[u] = *reinterpret_cast<const f32x4*>(slot + lane * 4);
+        nx1[u] = *reinterpret_cast<const f32x4*>(slot + 256 + lane * 4);
+        nqr[u] = *reinterpret_cast<const f32x4*>(slot + 512 + ts * 4);
     };
     // EMBED: x0 of a pair is two table rows; its residues are requested two iterations ahead and the rows read
     // from LDS one iteration ahead (residue load -> LDS read -> use is a dependent chain: inside one iteration
@@ -1428,7 +1434,7 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
     stage(p0, 0);
     if (RING) {
 #pragma unroll
-        for (int i = 0; i < RING; ++i) issue(p0 + i);
+        for (int i = 0; i < RING; ++i) issue(p0 + i, lane_off0);
     } else {
         fetch(p0, 0); fetch(p0 + 1, 1);
     }
@@ -1447,10 +1453,24 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
       for (int p = pt; p < pe; p += 2) {
         const bool two = p + 1 < pe;                       // wave-uniform (an odd group end leaves one pair)
         f32x4 xv0[2], xv1[2], qr[2];
+        f32x4 mpre[8];              // RING: the first pair's matrix rows, requested before the refill (see below)
         if (RING) {
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RING > 2 ? RING - 2 : 0)) : "memory");
             take(p, 0); take(p + 1, 1);
-            issue(p + RING); issue(p + RING + 1);           // into the two slots just read
+            // (the refill writes LDS, so hipcc keeps every later LDS read behind it: the first pair's matrix rows are
+            // requested HERE, and fly while the refill waits for the ring reads in front of them)
+            const float* m = mt + (p - pt) * MROW + 8 * cl;
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                mpre[2 * hh] = *reinterpret_cast<const f32x4*>(m + hh * 64);
+                mpre[2 * hh + 1] = *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
+            }
+            size_t lo = lane_off0;
+            // (the matrix rows are operands too: one wait covers all fourteen reads, and the arithmetic starts right
+            // behind the refill's six issue slots instead of behind a second LDS round trip)
+            asm("" : "+v"(lo) : "v"(nx0[0]), "v"(nx1[0]), "v"(nqr[0]), "v"(nx0[1]), "v"(nx1[1]), "v"(nqr[1]),
+                                "v"(mpre[0]), "v"(mpre[1]), "v"(mpre[2]), "v"(mpre[3]), "v"(mpre[4]), "v"(mpre[5]), "v"(mpre[6]), "v"(mpre[7]));
+            issue(p + RING, lo); issue(p + RING + 1, lo);   // into the two slots just read
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) { qr[u] = nqr[u]; xv0[u] = nx0[u]; xv1[u] = nx1[u]; }
@@ -1468,8 +1488,8 @@ __global__ void __launch_bounds__(256, PF_CS_WAVES) k_colstats(ColStatsArgs a) {
             f32x2 y[4] = {f32x2{br0[0], br0[1]}, f32x2{br0[2], br0[3]}, f32x2{br1[0], br1[1]}, f32x2{br1[2], br1[3]}};
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + hh * 64);
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
+                const f32x4 m0 = (RING && u == 0) ? mpre[2 * hh] : *reinterpret_cast<const f32x4*>(m + hh * 64);
+                const f32x4 m1 = (RING && u == 0) ? mpre[2 * hh + 1] : *reinterpret_cast<const f32x4*>(m + hh * 64 + 4);
                 const f32x2 qh = f32x2{qr[u][hh], qr[u][hh]};
                 y[0] = pk_fma(qh, f32x2{m0[0], m0[1]}, y[0]);
                 y[1] = pk_fma(qh, f32x2{m0[2], m0[3]}, y[1]);
