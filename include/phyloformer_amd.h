@@ -233,7 +233,10 @@ int pf_selftest(pf_handle_t* h, float* out);
  * stand-alone operator with the module's call surface.  x, y: float [B][R][C][64]; attention runs
  * along C, independently for every (b, r) and each of the 4 heads.  Weights are nn.Linear tensors
  * ([out][in] row-major + bias).  The object shares its parent handle's device and stream and must be
- * destroyed before it. */
+ * destroyed before it.
+ * Range (ABI 5): every contraction splits its operands into two fp16 limbs, so x, the weights and the
+ * q / k / v projections must stay below 65504 in magnitude (any LayerNorm-ed activation does, by orders of
+ * magnitude); beyond it the result is inf / NaN, not a wrong number. */
 typedef struct pf_mha_weights_t {
     int32_t n_heads;     /* 4 */
     int32_t embed_dim;   /* 64 */
