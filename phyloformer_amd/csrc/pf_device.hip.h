@@ -252,10 +252,9 @@ __device__ __forceinline__ float gelu_scaled(float x) {
     p = fmaf(p, u, -0.00003762f);                       // log2(2 Q): constant term of log2 Q plus one
     return fmaf(u, 1.f - __builtin_amdgcn_exp2f(p), x);
 }
-// (g0, g1) -> packed 16-bit pairs hi = h16(g), lo = h16(g - hi).  The residual g - hi comes from
-// v_dot2c_f32_{f16,bf16} (g += hi.lo * -1 + hi.hi * 0): one 4.5-cycle op instead of unpack (4.2) + subtract
-// (2.9), bit-identical to the fp32 subtraction (tools/dot2c_test.hip, tools/f16_probe.hip - subnormal hi
-// included), and it overlaps with MFMA.
+// (g0, g1) -> packed 16-bit pairs hi = h16(g), lo = h16(g - hi).  The residual g - hi comes from v_fma_mix_f32 (fp16)
+// or from v_dot2c_f32_bf16 (bf16 builds: g += hi.lo * -1 + hi.hi * 0, one 4.5-cycle op instead of unpack (4.2) +
+// subtract (2.9), bit-identical to the fp32 subtraction, tools/dot2c_test.hip).
 __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out, unsigned& lo_out) {
     const h16x2 h2 = {(h16_t)g0, (h16_t)g1};
     const unsigned hb = __builtin_bit_cast(unsigned, h2);
@@ -267,11 +266,22 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
 #define PF_DOT2C_PRE ""
 #define PF_DOT2C_POST "\n\ts_nop 3"
 #endif
-#ifdef PF_SPLIT_NODOT
+#if PF_F16 && !defined(PF_SPLIT_DOT2C) && !defined(PF_SPLIT_NODOT)
+    // fp16 (the default): v_fma_mix_f32 reads a half straight out of the packed register (op_sel picks it) and returns
+    // g - hi = hi * -1 + g in ONE ordinary VALU instruction - bit-identical to unpack + subtract on 2^20 values,
+    // subnormal hi included, interlocked like any VALU result (tools/f16_probe.hip) - where the bf16 kernels of rounds
+    // 1-5 needed v_dot2c_f32_bf16, a matrix-side op with a software-managed hazard: k_main -3 %, the forward +1.9 %
+    // against v_dot2c_f32_f16 (-DPF_SPLIT_DOT2C; profiles/r06m_ab_fmamix.txt).  Separate non-volatile statements, so
+    // the scheduler places them like its own instructions.  (Writing the lo limb straight from the FMA -
+    // v_fma_mixlo_f16 / v_fma_mixhi_f16, one instruction less per pair, equally exact - was slower: the read-modify-
+    // write of the packed destination costs k_main<MID, flat> its last registers, profiles/r06n_ab_mixlo.txt.)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(g0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(g1));
+#elif defined(PF_SPLIT_NODOT)
     // same residual through plain VALU (unpack / subtract): two more instructions per pair, but
     // unlike v_dot2c (matrix-side datapath) they can issue in the shadow of another wave's MFMA
-    r0 = g0 - (float)h2[0];
-    r1 = g1 - (float)h2[1];
+    r0 = fmaf((float)h2[0], -1.f, g0);
+    r1 = fmaf((float)h2[1], -1.f, g1);
 #else
     asm(PF_DOT2C_PRE PF_DOT2C " %0, %2, %4\n\t" PF_DOT2C " %1, %3, %4" PF_DOT2C_POST
                  : "+v"(r0), "+v"(r1) : "s"(PF_NEG1_LO), "s"(PF_NEG1_HI), "v"(hb));
@@ -283,12 +293,12 @@ __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out,
 __device__ __forceinline__ void gelu_split_pair(float x0, float x1, unsigned& hi_out, unsigned& lo_out) {   // tools/
     split_pair(gelu_scaled(x0), gelu_scaled(x1), hi_out, lo_out);
 }
-// split 8 floats into hi + lo fragments (x ~= hi + lo to 2^-22 relative in fp16, 2^-17 in bf16).  The eight
-// v_dot2c residuals are issued back to back in one asm block: each then sits >= 2 instructions ahead of
-// the first reader of its result, and a single s_nop covers the last one - instead of one pad per
-// pair as in split_pair (the pads alone were ~3 % of k_main's issue slots).
+// split 8 floats into hi + lo fragments (x ~= hi + lo to 2^-22 relative in fp16, 2^-17 in bf16).  fp16: four
+// split_pair()s.  The v_dot2c variants issue their eight residuals back to back in one asm block: each then sits
+// >= 2 instructions ahead of the first reader of its result, and a single s_nop covers the last one - instead of
+// one pad per pair as in split_pair (the pads alone were ~3 % of k_main's issue slots).
 __device__ __forceinline__ void split8(const float* v, frag_t& hi, frag_t& lo) {
-#ifdef PF_SPLIT_NODOT
+#if defined(PF_SPLIT_NODOT) || (PF_F16 && !defined(PF_SPLIT_DOT2C))
     u32x4 h, l;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -55,7 +55,8 @@ __global__ void k_split(const float* in, unsigned* out, int n) {
     const unsigned hb = __builtin_bit_cast(unsigned, hv);
     float r0 = g0, r1 = g1;
     // the dependent reader right behind the dot2c, NOPS wait states apart (NOPS < 0: none)
-    if (NOPS < 0)
+    if (NOPS >= 4) {
+    } else if (NOPS < 0)
         asm volatile("v_dot2c_f32_f16 %0, %2, %4\n\tv_dot2c_f32_f16 %1, %3, %4\n\tv_mul_f32 %1, 1.0, %1\n\tv_mul_f32 %0, 1.0, %0"
                      : "+v"(r0), "+v"(r1) : "s"(0x0000bc00u), "s"(0xbc000000u), "v"(hb));
     else if (NOPS == 0)
@@ -70,10 +71,25 @@ __global__ void k_split(const float* in, unsigned* out, int n) {
     else
         asm volatile("v_dot2c_f32_f16 %0, %2, %4\n\tv_dot2c_f32_f16 %1, %3, %4\n\ts_nop 3\n\tv_mul_f32 %1, 1.0, %1\n\tv_mul_f32 %0, 1.0, %0"
                      : "+v"(r0), "+v"(r1) : "s"(0x0000bc00u), "s"(0xbc000000u), "v"(hb));
+    if (NOPS == 4) {        // v_fma_mix_f32 instead of v_dot2c: hi read as a half out of the packed register, reader back to back
+        r0 = g0; r1 = g1;
+        asm volatile("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_mul_f32 %1, 1.0, %1\n\tv_mul_f32 %0, 1.0, %0"
+                     : "=&v"(r0), "=&v"(r1) : "v"(hb), "v"(g0), "v"(g1));
+    }
     const float s0 = g0 - (float)hv[0], s1 = g1 - (float)hv[1];               // v_cvt_f32_f16 + v_sub_f32
     const h2 lv = {(_Float16)r0, (_Float16)r1};
     out[6 * i] = hb;
-    out[6 * i + 1] = __builtin_bit_cast(unsigned, lv);
+    unsigned lbits = __builtin_bit_cast(unsigned, lv);
+    if (NOPS == 5) {        // the residual AND its conversion in one instruction per value: v_fma_mixlo_f16 / v_fma_mixhi_f16
+        unsigned l;
+        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(l) : "v"(hb), "v"(g0), "v"(g1));
+        lbits = l;
+        r0 = g0 - (float)hv[0]; r1 = g1 - (float)hv[1];
+    }
+    out[6 * i + 1] = lbits;
     out[6 * i + 2] = __float_as_uint(r0); out[6 * i + 3] = __float_as_uint(r1);
     out[6 * i + 4] = __float_as_uint(s0); out[6 * i + 5] = __float_as_uint(s1);
 }
@@ -184,12 +200,14 @@ int main(int argc, char** argv) {
         hipMalloc((void**)&di, n * 4); hipMalloc((void**)&dou, (size_t)3 * n * 4);
         hipMemcpy(di, in.data(), n * 4, hipMemcpyHostToDevice);
         std::vector<unsigned> out((size_t)3 * n);
-        for (int nops = -1; nops <= 3; ++nops) {
+        for (int nops = -1; nops <= 5; ++nops) {
             if (nops < 0) hipLaunchKernelGGL(k_split<-1>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
             else if (nops == 0) hipLaunchKernelGGL(k_split<0>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
             else if (nops == 1) hipLaunchKernelGGL(k_split<1>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
             else if (nops == 2) hipLaunchKernelGGL(k_split<2>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
-            else hipLaunchKernelGGL(k_split<3>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
+            else if (nops == 3) hipLaunchKernelGGL(k_split<3>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
+            else if (nops == 4) hipLaunchKernelGGL(k_split<4>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
+            else hipLaunchKernelGGL(k_split<5>, dim3(n / 2 / 256), dim3(256), 0, 0, di, dou, n);
             hipMemcpy(out.data(), dou, out.size() * 4, hipMemcpyDeviceToHost);
             long bad_cvt = 0, bad_dot = 0, bad_rec = 0, sub_hi = 0, finite = 0;
             double worst_rel = 0, worst_abs = 0;
@@ -206,6 +224,7 @@ int main(int argc, char** argv) {
                         if (bad_dot < 4) printf("   dot2c mismatch g=%a hi=%04x: dot2c %a  sub %a\n", gv, hb, __builtin_bit_cast(float, out[6 * i + 2 + j]), __builtin_bit_cast(float, out[6 * i + 4 + j]));
                         ++bad_dot;
                     }
+                    if (nops == 5 && lb != f2h(gv - hf)) { if (bad_dot < 4) printf("   mixlo/hi lo limb %04x != RNE(g - hi) %04x for g=%a\n", lb, f2h(gv - hf), gv); ++bad_dot; }
                     const double rec = (double)hf + (double)h2f(lb), err = std::fabs((double)gv - rec);
                     const double bound = std::fmax(std::ldexp(std::fabs((double)gv), -22) * 1.0001, std::ldexp(1.0, -25));
                     if (err > bound) { if (bad_rec < 4) printf("   hi+lo off: g=%a err %.3g bound %.3g\n", gv, err, bound); ++bad_rec; }
@@ -213,7 +232,7 @@ int main(int argc, char** argv) {
                 }
             printf("%s (reader %s): cvt_pk vs host RNE mismatches %ld / %d;  dot2c != sub: %ld;  hi+lo outside max(2^-22|g|, 2^-25): %ld "
                    "(worst rel %.3g = 2^%.2f for |g| >= 1/8, worst abs %.3g = 2^%.2f below; %ld subnormal hi among %ld finite)\n",
-                   nops < 0 ? "B/C/D" : "  C  ", nops < 0 ? "back to back" : nops == 0 ? "after s_nop 0" : nops == 1 ? "after s_nop 1, last result first" : nops == 2 ? "after s_nop 1, as split8 reads" : "after s_nop 3", bad_cvt, n, bad_dot, bad_rec,
+                   nops < 0 ? "B/C/D" : "  C  ", nops < 0 ? "back to back" : nops == 0 ? "after s_nop 0" : nops == 1 ? "after s_nop 1, last result first" : nops == 2 ? "after s_nop 1, as split8 reads" : nops == 3 ? "after s_nop 3" : nops == 4 ? "v_fma_mix_f32 instead of v_dot2c, back to back" : "lo limb by v_fma_mixlo/mixhi_f16", bad_cvt, n, bad_dot, bad_rec,
                    worst_rel, std::log2(worst_rel), worst_abs, std::log2(worst_abs), sub_hi, finite);
         }
     }
