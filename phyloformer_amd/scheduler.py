@@ -190,8 +190,8 @@ class DirectoryRunner:
         trees = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.nj.nwk") for g in group] if self.trees else None
         # (at most 4 threads: creating files in ONE directory from 8 / 16 threads is a lock convoy on the directory -
         # 4,096 outputs took 0.98 / 1.19 s instead of 0.01 s, profiles/r05c_cli_bench.txt)
-        # (with trees the neighbour joining - O(N^3) per file - is most of the work: all I/O threads)
-        write_phylip([g[1] for g in group], n, preds, outs, min(self.io_threads, 4) if trees is None else self.io_threads, trees)
+        cap = int(os.environ.get("PF_WRITER_THREADS", "4"))
+        write_phylip([g[1] for g in group], n, preds, outs, max(1, min(self.io_threads, cap)), trees)
 
     def _gpu_worker(self, engine, jobs: "queue.Queue", writers, pending, errors: list):
         while True:

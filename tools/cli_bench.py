@@ -14,7 +14,9 @@ ap.add_argument("--extra", default="")
 ap.add_argument("--trees", action="store_true", help="pass -t: <stem>.nj.nwk beside every <stem>.phy")
 a = ap.parse_args()
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tmp = tempfile.mkdtemp(prefix="pfcli_")
+# (tmpfs when there is one: the box's overlay file system throttles after the first few thousand small files - a second
+# run in the same box measured 3,100 alignments/s with or without trees where the first made 10,500; profiles/r06r_*)
+tmp = tempfile.mkdtemp(prefix="pfcli_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and not os.environ.get("PF_CLI_BENCH_TMP") else os.environ.get("PF_CLI_BENCH_TMP"))
 ind, outd = os.path.join(tmp, "in"), os.path.join(tmp, "out")
 os.makedirs(ind)
 base = simulate_batch(8, a.seqs, a.sites, seed=3)
