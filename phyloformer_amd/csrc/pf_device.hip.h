@@ -256,6 +256,13 @@ __device__ __forceinline__ float gelu_scaled(float x) {
 // or from v_dot2c_f32_bf16 (bf16 builds: g += hi.lo * -1 + hi.hi * 0, one 4.5-cycle op instead of unpack (4.2) +
 // subtract (2.9), bit-identical to the fp32 subtraction, tools/dot2c_test.hip).
 __device__ __forceinline__ void split_pair(float g0, float g1, unsigned& hi_out, unsigned& lo_out) {
+#if PF_F16
+    // (opaque copies: hipcc otherwise fuses the conversion of the hi limb into the producer of g - fpround(fma) ->
+    // v_fma_mixlo_f16 + v_fma_mixhi_f16, two instructions per pair that repeat the GELU's last FMA - where one
+    // v_cvt_pk_f16_f32 per pair does: 8 instructions of 231 in the hidden loop, tools/isa_histogram.py)
+    asm("" : "+v"(g0));
+    asm("" : "+v"(g1));
+#endif
     const h16x2 h2 = {(h16_t)g0, (h16_t)g1};
     const unsigned hb = __builtin_bit_cast(unsigned, h2);
     float r0 = g0, r1 = g1;

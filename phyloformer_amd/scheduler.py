@@ -189,7 +189,9 @@ class DirectoryRunner:
         outs = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.phy") for g in group]
         trees = [os.path.join(self.out_dir, f"{Path(g[0]).stem}.nj.nwk") for g in group] if self.trees else None
         # (at most 4 threads: creating files in ONE directory from 8 / 16 threads is a lock convoy on the directory -
-        # 4,096 outputs took 0.98 / 1.19 s instead of 0.01 s, profiles/r05c_cli_bench.txt)
+        # 4,096 outputs took 0.98 / 1.19 s instead of 0.01 s, profiles/r05c_cli_bench.txt.  The neighbour joining of
+        # --trees rides on the same threads: 64 us per 20-taxon tree, 18 ms at 200 taxa, against 90 us / 22 ms of GPU time
+        # per alignment.  PF_WRITER_THREADS moves the cap for experiments, profiles/r06r_cli_bench_overlay_writer_threads.txt.)
         cap = int(os.environ.get("PF_WRITER_THREADS", "4"))
         write_phylip([g[1] for g in group], n, preds, outs, max(1, min(self.io_threads, cap)), trees)
 

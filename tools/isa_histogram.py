@@ -17,8 +17,7 @@ def main():
     want = sys.argv[1]
     loop = int(sys.argv[sys.argv.index("--loop") + 1]) if "--loop" in sys.argv else None
     asm = os.path.join(tempfile.gettempdir(), "pf_lib_isa.s")
-    cmd = [B.hipcc_path(), f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-Wno-unused-value",
-           "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", asm, B.SOURCES[0]]
+    cmd = [B.hipcc_path(), *B.COMMON, *B.UNITS["pf_lib.hip"], "-S", "--cuda-device-only", "-o", asm, os.path.join(B.CSRC, "pf_lib.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode:
         sys.stderr.write(res.stderr[-3000:]); sys.exit(1)
