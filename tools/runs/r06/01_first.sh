@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, first GPU call: the fp16 probe, the hidden loop's energy in both operand formats, the GPU suite on the fp16
 # build, an alternating A/B of the fp16 / bf16 / round-5 builds and the 741-case adversarial study on each.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06a; mkdir -p $O
 tools/f16_probe 3 > $O/f16_probe.txt 2>&1
 ( for r in 1 2; do for f in 0 1; do echo "== PF_F16=$f"; PF_PLAIN=1 timeout 120 tools/ffn3_bench_fmt$f energy 4 2>&1 | grep -E "^energy"; done; done ) > $O/ffn3_energy.txt 2>&1

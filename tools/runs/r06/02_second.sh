@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, GPU call: packed-fp32 k_colstats and the hazard-safe split8 against the first fp16 build and the bf16 build.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06c; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 --deselect tests/test_gpu_precise.py::test_soak_every_accepted_shape_within_the_reference_error > $O/pytest.txt 2>&1
 cp gpurun_out/parity_errors.json $O/ 2>/dev/null

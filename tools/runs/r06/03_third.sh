@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06d; mkdir -p $O
 python tools/kernel_ab.py colstats libphyloformer_amd.so lib_f16a.so > $O/colstats_ab_one_stream.txt 2>&1
 python tools/kernel_ab.py main libphyloformer_amd.so lib_f16a.so lib_bf16.so > $O/main_ab_one_stream.txt 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06e; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_precise.py -m gpu -q -x -k "ring_prefetch or fp16_operand or errors_mirror or batch_invariance or configs" > $O/pytest_a.txt 2>&1
 tail -5 $O/pytest_a.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # full GPU suite (soak included) with the L < 32 routing rule, then the soak with six other seeds
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06f; mkdir -p $O
 timeout 1700 python -m pytest tests -m gpu -q --maxfail=20 > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6 profile round: kernel statistics, PMC passes, bench line; CLI files -> files with and without --trees; the
 # softmax operator; the adversarial study as the product routes it; the soak with twelve more seeds.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06g; mkdir -p $O
 bash tools/profile_round.sh r06g > $O/profile_round.log 2>&1
 ( cd /tmp && TMPDIR=/tmp rocprofv3 --list-avail > $GRAFT_REPO_ROOT/$O/avail.txt 2>&1 )

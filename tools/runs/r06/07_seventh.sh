@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06h; mkdir -p $O
 ( for l in libphyloformer_amd.so lib_r6m8.so lib_r4m8.so lib_r2m16.so libphyloformer_amd.so lib_r6m8.so; do python tools/kernel_ab.py colstats $l | head -3; done ) > $O/colstats_variants.txt 2>&1
 cat $O/colstats_variants.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06i; mkdir -p $O
 bash tools/pmc_colstats.sh r06i/pmc_colstats > $O/pmc_colstats.log 2>&1
 timeout 1700 python -m pytest tests -m gpu -q --maxfail=20 > $O/pytest.txt 2>&1

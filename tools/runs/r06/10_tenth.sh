@@ -1,7 +1,7 @@
 #!/bin/bash
 # final evidence of round 6 on the final kernels: kernel statistics, PMC passes (k_main traffic tied to the kernel hash),
 # the bench line, k_colstats' counters for both prefetch variants, the parity table of the full suite
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06k; mkdir -p $O
 bash tools/profile_round.sh r06k > $O/profile_round.log 2>&1
 bash tools/pmc_colstats.sh r06k/pmc_colstats > $O/pmc_colstats.log 2>&1

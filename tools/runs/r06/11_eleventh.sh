@@ -1,6 +1,6 @@
 #!/bin/bash
 # final evidence after the v_fma_mix_f32 split: A/B against the v_dot2c variant, full suite, profile round, studies
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06p; mkdir -p $O
 PF_AB_STEPS=10 python tools/flag_compare.py libphyloformer_amd.so lib_dot2c.so lib_bf16.so libphyloformer_amd.so lib_dot2c.so lib_bf16.so > $O/ab_fmamix_dot2c_bf16.txt 2>&1; cat $O/ab_fmamix_dot2c_bf16.txt
 timeout 1700 python -m pytest tests -m gpu -q --maxfail=20 > $O/pytest.txt 2>&1; grep -E "passed|failed" $O/pytest.txt

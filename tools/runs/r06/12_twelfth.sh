@@ -1,6 +1,6 @@
 #!/bin/bash
 # final evidence (the build with opaque split inputs): suite, profile round, studies, MHA / CLI refresh
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 O=gpurun_out/r06u; mkdir -p $O
 timeout 1700 python -m pytest tests -m gpu -q --maxfail=20 > $O/pytest.txt 2>&1; grep -E "passed|failed" $O/pytest.txt
 cp gpurun_out/parity_errors.json $O/ 2>/dev/null
