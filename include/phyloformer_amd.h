@@ -127,11 +127,19 @@ const char* pf_last_error(const pf_handle_t* h);
  *                      3-9 x slower).  The choice never depends on the batch.  Above the option: a checkpoint or
  *                      shape whose operands could overflow the default kernels' fp16 MFMA operands (weights ~ 1000 x
  *                      the trained ones, more than 2^20 sites) always runs in float64.
+ *   "recheck_above" int  range re-check of pf_forward / pf_forward_sharded (the host-buffer entry points; only while
+ *                      "precise" is -1): an alignment whose largest predicted distance exceeds this many substitutions
+ *                      per site (default 8; 0 = off), or is not finite, is computed again on the float64 kernels before
+ *                      the call returns.  An absolute tolerance of 1e-4 on a value of 10 asks for 1e-5 relative - the
+ *                      rounding level of fp32 arithmetic itself, the reference's included; alignments stay far below
+ *                      (<= 5 on the reference's test data), uniformly random residues do not (9-13).  Per alignment,
+ *                      never a function of the batch; pf_profile_get("rechecked") counts them.  The device entry
+ *                      points do not re-check (their results never pass through the host).
  */
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
 
 /* Forward pass.  idx: host uint8 [B][N][L]; out: host float [B][P].
- * Synchronous: returns after `out` is filled.  Never communicates: on a handle that carries a
+ * Synchronous: returns after `out` is filled (and re-checked, option "recheck_above").  Never communicates: on a handle that carries a
  * communicator (pf_comm_init) pf_forward / pf_forward_device still process this rank's own
  * alignments only (alignment-level data parallelism); collectives belong to pf_forward_sharded*.
  * Errors: PF_EINVAL for B < 1, N < 2, L < 1, N > max_seqs, or an index > 21. */
@@ -193,7 +201,8 @@ int pf_memcpy_d2h(pf_handle_t* h, void* dst, const void* src, size_t bytes);
 /* Per-kernel HIP-event timing ("profile" = 1).  Names: "embed", "rowfin",
  * "colstats", "colfin", "main", "allreduce", "mha_qkv", "mha_attn", "mha_out".  Totals accumulate
  * until reset.  "collectives" returns the number of all-reduces issued since the last reset in
- * *launches (counted always, no profiling option needed; *total_ms = 0). */
+ * *launches (counted always, no profiling option needed; *total_ms = 0); "rechecked" likewise the number of
+ * alignments the range re-check (option "recheck_above") computed again on the float64 kernels. */
 int pf_profile_reset(pf_handle_t* h);
 int pf_profile_get(pf_handle_t* h, const char* kernel, int64_t* launches, double* total_ms);
 

@@ -298,6 +298,10 @@ class Engine:
         """All-reduces issued by this handle since the last ``profile_reset`` (always counted)."""
         return self.profile_get("collectives")[0]
 
+    def rechecked_count(self) -> int:
+        """Alignments the range re-check (option "recheck_above") recomputed in float64 since ``profile_reset``."""
+        return self.profile_get("rechecked")[0]
+
     def comm_info(self) -> dict:
         """Path and version of the librccl the native library resolved (loads it if necessary)."""
         buf = C.create_string_buffer(512)

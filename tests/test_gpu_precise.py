@@ -164,6 +164,46 @@ def _soak_cases(n_cases, seed):
         yield c, CKPTS[c % len(CKPTS)], n, l, b, mode, int(rng.integers(1 << 30))
 
 
+def test_range_recheck_sends_saturated_distances_to_float64(engines, weights):
+    """Round 6: the one soak violation in 11,520 cases of 48 seeds (seed 27, case 114: 33 x 33 uniformly random residues,
+    pf_selreg - predicted distances up to 13.4, the fp32 reference 4.7e-5 from its float64 evaluation, the default kernels
+    1.12e-4 from the fp32 reference = 8e-6 of the largest distance).  An ABSOLUTE 1e-4 on values of 10 is fp32's own
+    rounding level, so the host entry points recompute any alignment whose largest distance exceeds 8 substitutions per
+    site (option "recheck_above") in float64: per alignment, batch-invariant, counted, and switched off with the option."""
+    ck, n, l, seed = "pf_selreg", 33, 33, 805854907
+    e, w = engines(ck), weights(ck).tensors
+    idx = np.random.default_rng(seed).integers(0, 22, (1, n, l)).astype(np.uint8)
+    f32, f64 = O.forward_batch(w, idx), _f64(w, idx)
+    assert float(f32.max()) > 8.0 and not _routed_to_float64(n, l)
+    bound = max(1e-4, 2.0 * float(np.abs(f32 - f64).max()))
+    try:
+        e.profile_reset()
+        got = e.forward(idx)
+        assert e.rechecked_count() == 1
+        assert float(np.abs(got - f64).max()) <= 1e-9 + 6e-8 * float(np.abs(f64).max())
+        assert float(np.abs(got - f32).max()) <= bound
+        # in a batch only that alignment is recomputed; its bits and its neighbours' bits do not depend on the company
+        sim = simulate_batch(2, n, l, seed=5)
+        assert float(O.forward_batch(w, sim).max()) < 8.0
+        batch = np.concatenate([sim[:1], idx, sim[1:]])
+        e.profile_reset()
+        gb = e.forward(batch)
+        assert e.rechecked_count() == 1
+        assert np.array_equal(gb[1], got[0])
+        assert np.array_equal(gb[[0, 2]], e.forward(sim)) and e.rechecked_count() == 1
+        # off: the default kernels' own result (fp32-level: within 2e-5 of the largest distance)
+        e.set_option("recheck_above", 0)
+        e.profile_reset()
+        raw = e.forward(idx)
+        assert e.rechecked_count() == 0
+        err = float(np.abs(raw - f32).max())
+        assert err <= 2e-5 * float(f32.max())
+        print(f"range re-check: default kernels {err:.3e} from the fp32 oracle at a largest distance of {float(f32.max()):.2f} "
+              f"(fp32 oracle {float(np.abs(f32 - f64).max()):.3e} from float64); recomputed: {float(np.abs(got - f32).max()):.3e}")
+    finally:
+        e.set_option("recheck_above", 8)
+
+
 def test_soak_every_accepted_shape_within_the_reference_error(engines, weights):
     """240 seeded cases over N in 2..40, L in {1, 2, 3, ..., 200}, batches of 1-3, all five
     checkpoints, as the product routes them.  Simulated alignments, with and without gaps (2/3 of the cases): the GPU is
