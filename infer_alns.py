@@ -63,7 +63,8 @@ def build_parser():
                              "of a synchronous forward, 1 = one launch sequence at a time")
     parser.add_argument("--precise", choices=["auto", "always", "never"], default="auto",
                         help="float64 kernels: auto = for alignments of fewer than 32 sites or 8,192 pair-site tokens (where the fp32 reference itself is "
-                             "ill-conditioned); always = every alignment (3-9 x slower); never = the split-fp16 MFMA kernels "
+                             "ill-conditioned) and, after the fact, for any alignment with a predicted distance above 8 substitutions per "
+                             "site (never an alignment; an absolute 1e-4 there is fp32's own rounding level); always = every alignment (3-9 x slower); never = the split-fp16 MFMA kernels "
                              "on every shape")
     parser.add_argument("--python-io", action="store_true",
                         help="use the pure-Python FASTA parser and PHYLIP writer instead of the native ones")

@@ -165,7 +165,7 @@ def _soak_cases(n_cases, seed):
 
 
 def test_range_recheck_sends_saturated_distances_to_float64(engines, weights):
-    """Round 6: the one soak violation in 11,520 cases of 48 seeds (seed 27, case 114: 33 x 33 uniformly random residues,
+    """Round 6: the one soak violation in 10,080 cases of 42 seeds (seed 27, case 114: 33 x 33 uniformly random residues,
     pf_selreg - predicted distances up to 13.4, the fp32 reference 4.7e-5 from its float64 evaluation, the default kernels
     1.12e-4 from the fp32 reference = 8e-6 of the largest distance).  An ABSOLUTE 1e-4 on values of 10 is fp32's own
     rounding level, so the host entry points recompute any alignment whose largest distance exceeds 8 substitutions per
