@@ -76,6 +76,33 @@ def test_rccl_single_rank_communicator(weights, golden):
     print("RCCL:", info)
 
 
+def test_range_recheck_of_a_sharded_call_runs_the_float64_collectives(weights):
+    """The range re-check (option "recheck_above", tests/test_gpu_precise.py) inside pf_forward_sharded over a real
+    single-rank communicator pair: the batch of three takes the default kernels' 14 collectives, then the one alignment
+    whose distances exceed 8 takes the float64 forward's 7 - the same alignments on every rank, since all ranks hold the
+    same all-reduced result - and the call returns pf_forward's bits."""
+    from phyloformer_amd.engine import Engine
+    n, l = 33, 33
+    sat = np.random.default_rng(805854907).integers(0, 22, (1, n, l)).astype(np.uint8)
+    sim = simulate_batch(2, n, l, seed=5)
+    batch = np.concatenate([sim[:1], sat, sim[1:]])
+    with Engine(weights("pf_selreg"), 0) as e:
+        ref = e.forward(batch)
+        assert e.rechecked_count() == 1 and float(ref[1].max()) > 8.0 and float(ref[[0, 2]].max()) < 8.0
+        e.set_option("force_rccl", 1)
+        e.comm_init(e.unique_id(), 0, 1)
+        e.profile_reset()
+        got = e.forward_sharded(batch, 0, l, l)
+        assert e.collective_count() == 14 + 7 and e.rechecked_count() == 1
+        e.set_option("recheck_above", 0)
+        e.profile_reset()
+        raw = e.forward_sharded(batch, 0, l, l)
+        assert e.collective_count() == 14 and e.rechecked_count() == 0
+        e.comm_destroy()
+    assert np.array_equal(got, ref)
+    assert np.array_equal(raw[[0, 2]], ref[[0, 2]]) and not np.array_equal(raw[1], ref[1])
+
+
 def test_partial_site_range_without_communicator_is_refused(weights, golden):
     """pf_forward_sharded with fewer sites than L_total and no communicator would return partial sums divided
     by L_total: PF_ESTATE instead."""
