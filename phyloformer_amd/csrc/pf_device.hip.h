@@ -833,9 +833,11 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
             if (MODE != MODE_LAST && !(a.ablate & 4)) {
                 // ---- statistics of the next block's row attention (attention.py:163-190)
                 // Wv' lo fragments (L2) are requested before the residual store for the same reason
+                // (the first WVLO_LDS of the eight live in LDS - all the image has room for; each fragment taken out of
+                // this stream is 1 KB of L2 reads per tile and wave less)
                 frag_t wl[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wl[i] = a.wv_lo[i * 64 + lane];
+                for (int i = WVLO_LDS; i < 8; ++i) wl[i] = a.wv_lo[i * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     // Branch-free store: a divergent `if (valid)` makes hipcc merge the vmcnt state of
@@ -871,8 +873,9 @@ __global__ void __launch_bounds__(MAIN_THREADS, MAIN_WAVES / 4) k_main(MainArgs 
 #pragma unroll
                         for (int T = 0; T < 2; ++T) {
                             const frag_t f_hi = wvp[(T * 4 + s) * 64];
-                            if (s == 0) mfma3_zero(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s], T == 1);
-                            else mfma3(va[T], f_hi, wl[T * 4 + s], xb_hi[s], xb_lo[s], T == 1);
+                            const frag_t f_lo = T * 4 + s < WVLO_LDS ? wvp[(FRAG_WVLO - FRAG_WV) + (T * 4 + s) * 64] : wl[T * 4 + s];
+                            if (s == 0) mfma3_zero(va[T], f_hi, f_lo, xb_hi[s], xb_lo[s], T == 1);
+                            else mfma3(va[T], f_hi, f_lo, xb_hi[s], xb_lo[s], T == 1);
                         }
                 }
 #pragma unroll

@@ -25,8 +25,9 @@ constexpr float LN_EPS = 1e-5f;
 //   W1' : [8 T][4 s][2 hi/lo][64 lanes]      64 KB   (FFN 64->256, LN affine folded)
 //   W2  : [2 To][16 s][2][64]                64 KB   (FFN 256->64)
 //   Woc : [2 To][4 s][2][64]                 16 KB   (column out_proj)
-//   Wv' : [2 T][4 s][64] hi only              8 KB   (next block's row V projection; lo from L2)
+//   Wv' : [2 T][4 s][64] hi only              8 KB   (next block's row V projection; lo: below / L2)
 //   Wqk : [4 s][2][16]                         2 KB   (next block's row q/k rows, 8 of 32 rows)
+//   Wv' lo : [WVLO_LDS of 2 T x 4 s][64]       4 KB   (the first four of the eight lo fragments; the rest from L2)
 //   consts (floats): b1'[256] | b2[64] | bqk[8] | head_w[64] | head_b[1] | pad | bo_col[64]
 constexpr int FRAG_W1 = 0;                                   // [8 T][4 s][2 hi/lo][64]
 constexpr int FRAG_W2 = FRAG_W1 + 8 * 4 * 2 * 64;            // [2 To][16 s][2][64]
@@ -34,12 +35,17 @@ constexpr int FRAG_WO = FRAG_W2 + 2 * 16 * 2 * 64;           // [2 To][4 s][2][6
 constexpr int FRAG_WV = FRAG_WO + 2 * 4 * 2 * 64;            // next row attn Wv' hi only: [2 T][4 s][64]
 constexpr int FRAG_QK = FRAG_WV + 2 * 4 * 64;                // next row attn [Wq';Wk'] rows 0..7 only:
                                                              //   [4 s][2 hi/lo][2 kgrp][8 rows]
-constexpr int FRAG_END = FRAG_QK + 4 * 2 * 16;               // in fragment (16-byte) units
+#ifndef PF_WVLO_LDS
+#define PF_WVLO_LDS 4        // of the 8 Wv' lo fragments per lane, how many live in LDS (what fits: 4 KB of the 4,288 B left)
+#endif
+constexpr int WVLO_LDS = PF_WVLO_LDS;
+constexpr int FRAG_WVLO = FRAG_QK + 4 * 2 * 16;              // the first WVLO_LDS of Wv' lo's [2 T][4 s] fragments: [..][64]
+constexpr int FRAG_END = FRAG_WVLO + WVLO_LDS * 64;          // in fragment (16-byte) units
 constexpr int WVLO_FRAGS = 2 * 4 * 64;                       // lo part of Wv', read from global
 constexpr int CONST_B1 = 0, CONST_B2 = 256, CONST_BQK = 320, CONST_HW = 328, CONST_HB = 392,
               CONST_BOC = 400;
 constexpr int CONST_LEN = 464;                                // floats
-constexpr int MAIN_LDS_BYTES = FRAG_END * 16 + CONST_LEN * 4; // 159,552 B of the 163,840 B LDS
+constexpr int MAIN_LDS_BYTES = FRAG_END * 16 + CONST_LEN * 4; // 163,648 B of the 163,840 B LDS (159,552 without Wv' lo)
 constexpr int MFRAG_PER_PAIR = 2 * 2 * 32;                    // row-mix fragments per pair (lanes h=0)
 
 constexpr int MAIN_THREADS = 512;  // 8 waves: two per SIMD so MFMA and VALU phases of different waves overlap

@@ -380,6 +380,7 @@ int prepare_weights(pf_handle* h, const pf_weights_t* w) {
         row_tail[k].assign((size_t)(FRAG_END - FRAG_WV) * 8, 0);
         std::vector<uint16_t> wvlo((size_t)WVLO_FRAGS * 8);
         pack_row_stats(wv.data(), wq.data(), wk.data(), row_tail[k].data(), wvlo.data());
+        std::copy(wvlo.begin(), wvlo.begin() + (size_t)WVLO_LDS * 64 * 8, row_tail[k].begin() + (size_t)(FRAG_WVLO - FRAG_WV) * 8);
         if ((rc = upload(h, wvlo, &d.wv_lo))) return rc;
         row_bqk[k].assign(8, 0.f);
         for (int i = 0; i < 4; ++i) { row_bqk[k][i] = bq[i]; row_bqk[k][4 + i] = bk[i]; }
