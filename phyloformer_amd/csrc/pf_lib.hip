@@ -212,7 +212,7 @@ struct pf_handle {
     // Range re-check of the host entry points (forward_host_impl): an alignment whose largest predicted distance exceeds
     // recheck_above substitutions per site is computed again on the float64 kernels (option "recheck_above", 0 = off;
     // only when "precise" is -1).  An ABSOLUTE bound of 1e-4 on a value of 10 asks for 1e-5 relative - fp32's own level,
-    // where the default kernels sit (<= 8.4e-6 of the largest distance in 10,080 soak cases) and where the fp32
+    // where the default kernels sit (<= 8.7e-6 of the largest distance in 21,600 soak cases) and where the fp32
     // reference itself is 5e-5 from its float64 evaluation; no alignment gets there (the reference's test data and
     // BASELINE's configurations end at 5.0), uniformly random residues do (9-13).
     double recheck_above = 8.0;
