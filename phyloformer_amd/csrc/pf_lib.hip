@@ -1025,18 +1025,21 @@ int forward_host_impl(pf_handle* h, const uint8_t* idx, int B, int N, int l_begi
         // all-reduced site sums through the same kernel), so all of them pick the same alignments and issue the same
         // collectives of the float64 forward.  A non-finite value is recomputed as well.
         std::vector<int> redo;
-        for (int b = 0; b < B; ++b) {
-            const float* ob = out + (size_t)b * P;
-            bool inside = true;
-            for (int p = 0; p < P; ++p) inside &= ob[p] <= (float)h->recheck_above;      // (false for NaN)
-            if (!inside) redo.push_back(b);
-        }
+        std::vector<uint8_t> sub;
+        std::vector<float> res;
+        const size_t per = (size_t)N * Lloc;
+        try {           // (nothing may throw across the C ABI)
+            for (int b = 0; b < B; ++b) {
+                const float* ob = out + (size_t)b * P;
+                bool inside = true;
+                for (int p = 0; p < P; ++p) inside &= ob[p] <= (float)h->recheck_above;      // (false for NaN)
+                if (!inside) redo.push_back(b);
+            }
+            sub.resize(redo.size() * per);
+            res.resize(redo.size() * (size_t)P);
+        } catch (const std::bad_alloc&) { return fail(h, PF_ENOMEM, "out of host memory in the range re-check"); }
         if (!redo.empty()) {
-            const size_t per = (size_t)N * Lloc, nr = redo.size();
-            std::vector<uint8_t> sub;
-            std::vector<float> res;
-            try { sub.resize(nr * per); res.resize(nr * (size_t)P); }
-            catch (const std::bad_alloc&) { return fail(h, PF_ENOMEM, "out of host memory in the range re-check"); }
+            const size_t nr = redo.size();
             for (size_t i = 0; i < nr; ++i)
                 if (per) std::memcpy(&sub[i * per], idx + (size_t)redo[i] * per, per);
             if (per) HIPCHK(h, hipMemcpyAsync(h->d_idx, sub.data(), nr * per, hipMemcpyHostToDevice, h->stream));
