@@ -135,6 +135,12 @@ const char* pf_last_error(const pf_handle_t* h);
  *                      (<= 5 on the reference's test data), uniformly random residues do not (9-13).  Per alignment,
  *                      never a function of the batch; pf_profile_get("rechecked") counts them.  The device entry
  *                      points do not re-check (their results never pass through the host).
+ * Test / tool switches, not part of the contract:
+ *   "colstats_ring" int  0 = k_colstats prefetches its rows through registers instead of the per-wave LDS ring (the
+ *                      same bits; A/B and counter runs)
+ *   "precise_ffn_valu" int 1 = the float64 FFN on the plain VALU kernel instead of the fp64 matrix cores (cross-check)
+ *   "phase_prof"  int  1 = in-kernel phase timers of k_main (pf_debug_read "phase_prof")
+ *   "ablate"      int  energy experiments: phases of k_main switched off - RESULTS INVALID
  */
 int pf_set_option(pf_handle_t* h, const char* key, int64_t value);
 

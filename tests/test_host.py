@@ -119,6 +119,18 @@ def test_abi_symbols_exported(repo):
     assert lib.pf_blob_len(6, 4, 64) == 308449
 
 
+def test_every_option_the_library_accepts_is_documented_in_the_header(repo):
+    """include/phyloformer_amd.h lists the options of pf_set_option; csrc/pf_lib.hip implements them: the same set."""
+    import re
+    h = open(os.path.join(repo, "include", "phyloformer_amd.h")).read()
+    blk = h[h.index("/* Options (before or between forwards):"):h.index("int pf_set_option")]
+    documented = set(re.findall(r'^ \*   "(\w+)"', blk, re.M))
+    src = open(os.path.join(repo, "phyloformer_amd", "csrc", "pf_lib.hip")).read()
+    fn = src[src.index("int pf_set_option("):]
+    implemented = set(re.findall(r'k == "(\w+)"', fn[:fn.index("\n}\n")]))
+    assert documented == implemented, (documented - implemented, implemented - documented)
+
+
 def test_no_cpu_fallback_without_gpu(weights):
     """On a machine without a gfx950 device pf_create must fail loudly."""
     import ctypes
